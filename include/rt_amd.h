@@ -1,0 +1,249 @@
+/*
+ * rt_amd.h - C ABI of the MI355X (gfx950) path-tracing hot path.
+ *
+ * The reference program has no plugin / FFI boundary: its hot path is reached
+ * by direct C++ member calls inside one translation unit
+ * (raytracer.cpp:1456-1503 pixel loop -> Scene::getColor :953 ->
+ * Scene::intersect :930 -> Sphere::intersect :883 / TriangleMesh::intersect
+ * :642).  This header is the boundary a maintainer of that program would bind
+ * instead: plain pointers and sizes, int status codes, no C++ or torch types.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative RT_E_* code otherwise;
+ *    rt_last_error() gives the message of the last failure on that context.
+ *  - all real-valued scene data is IEEE binary64: the reference computes in
+ *    double everywhere (raytracer.cpp:29-60) and hit identity must match it
+ *    bit for bit.
+ *  - host arrays handed to rt_upload_scene are copied to HBM before the call
+ *    returns; the caller keeps ownership.
+ *  - one render in flight per context; a context is bound to one HIP device
+ *    and one HIP stream.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_E_INVALID -1  /* bad argument / inconsistent scene description  */
+#define RT_E_DEVICE -2   /* HIP runtime failure (message has the HIP error) */
+#define RT_E_NOMEM -3    /* device allocation failed                       */
+#define RT_E_STATE -4    /* call made in the wrong state (no scene, ...)   */
+
+/* material flags (Object::isMirror / isTransparent, raytracer.cpp:156-157) */
+#define RT_MAT_MIRROR 1
+#define RT_MAT_TRANSPARENT 2
+
+/* Sphere (raytracer.cpp:874-921). object_id is the position of the sphere in
+ * Scene::objects (raytracer.cpp:927): the lowest id wins exact ties in t
+ * (strict '<' at raytracer.cpp:938). */
+typedef struct rt_sphere {
+    double O[3];
+    double R;
+    double albedo[3];
+    int32_t flags;
+    int32_t object_id;
+} rt_sphere; /* 64 bytes */
+
+/* Flattened BVH node.  One record holds the boxes of BOTH children of one
+ * inner Noeud (raytracer.cpp:190-196), because the reference tests fg's box
+ * and then fd's box when it pops their parent (raytracer.cpp:656-665).
+ * box = {min x,y,z, max x,y,z}.  Child c is an inner node when n? == 0 (then
+ * ? is a node index) and a leaf when n? > 0 (then ? is the index of its first
+ * triangle in the permuted triangle array, n? triangles). */
+typedef struct rt_bvh_node {
+    double boxL[6];
+    double boxR[6];
+    int32_t L, R;
+    int32_t nL, nR;
+    int32_t pad[4];
+} rt_bvh_node; /* 128 bytes */
+
+/* Triangle, in the order buildBVH leaves TriangleMesh::indices
+ * (raytracer.cpp:269-278).  A, e1 = B-A, e2 = C-A are what the test at
+ * raytracer.cpp:673-677 derives from the three vertices; they do not depend on
+ * the ray, so they are formed once on the host with the same two subtractions.
+ * orig_id = index of the triangle in OBJ face-fan order (before buildBVH). */
+typedef struct rt_tri {
+    double A[3];
+    double e1[3];
+    double e2[3];
+    int32_t orig_id;
+    int32_t pad;
+} rt_tri; /* 80 bytes */
+
+/* Shading attributes of a triangle, same index as rt_tri: the three vertex
+ * normals and uvs gathered through TriangleIndices (raytracer.cpp:694, :702)
+ * and the usemtl ordinal 'group' that selects the texture (:700-701). */
+typedef struct rt_tri_attr {
+    double n[3][3];
+    double uv[3][2];
+    int32_t group;
+    int32_t pad;
+} rt_tri_attr; /* 128 bytes */
+
+/* TriangleMesh as an Object (raytracer.cpp:208-218, :862-871). The root
+ * Noeud's box is tested first (raytracer.cpp:644). root_count > 0 means the
+ * root itself is a leaf holding triangles [root, root+root_count). */
+typedef struct rt_mesh {
+    double root_box[6];
+    double albedo[3];
+    int32_t flags;
+    int32_t object_id;
+    int32_t root;
+    int32_t root_count;
+    int32_t first_tex; /* index of textures[0] of this mesh in rt_scene_desc.tex */
+    int32_t n_tex;     /* textures.size(); 0 -> colour = albedo (raytracer.cpp:697,:719) */
+    int32_t first_tri; /* range of this mesh in the triangle arrays */
+    int32_t n_tris;
+    int32_t max_depth; /* deepest leaf, root = 0 */
+    int32_t pad;
+} rt_mesh; /* 112 bytes */
+
+/* RGB8 texture as stbi_load(...,3) returns it (raytracer.cpp:762): row 0 is
+ * the top row, 3 bytes per texel. offset is into rt_scene_desc.texels. */
+typedef struct rt_texture {
+    int64_t offset;
+    int32_t W, H;
+} rt_texture;
+
+typedef struct rt_scene_desc {
+    int32_t n_spheres;
+    int32_t n_meshes;
+    const rt_sphere *spheres;
+    const rt_mesh *meshes;
+    int64_t n_nodes;
+    const rt_bvh_node *nodes;
+    int64_t n_tris;
+    const rt_tri *tris;
+    const rt_tri_attr *attrs;
+    int32_t n_tex;
+    int32_t pad;
+    const rt_texture *tex;
+    const uint8_t *texels;
+    int64_t texel_bytes;
+    /* 256-entry table pow(i/255., 2.2) (raytracer.cpp:713-715). The caller
+     * fills it with its libm so texture colours match the CPU bit for bit;
+     * pass NULL to have the library compute it with the host libm. */
+    const double *srgb_lut;
+    double I;    /* Scene::I, raytracer.cpp:929, :1164 */
+    double L[3]; /* Scene::L, raytracer.cpp:928, :1165 */
+} rt_scene_desc;
+
+/* Camera of the pixel loop (raytracer.cpp:1441-1453, :1475-1483).
+ * right/up/view are the basis vectors main() builds from the two angles;
+ * zdist = W / (2 tan(fov/2)); focus = 55 (:1479); aa_sigma = 0.25 (:1468);
+ * dof_sigma = 0.01 "off" / 1 "on" (:1472). */
+typedef struct rt_camera {
+    double C[3];
+    double right[3];
+    double up[3];
+    double view[3];
+    double zdist;
+    double focus;
+    double aa_sigma;
+    double dof_sigma;
+} rt_camera;
+
+/* render flags */
+#define RT_F_POINT_LIGHT 1u /* direct light of raytracer.cpp:1040-1055 (point light, hard shadow); objects[0] is then an ordinary object */
+#define RT_F_NO_INDIRECT 2u /* skip the indirect bounce of raytracer.cpp:1086-1088 */
+#define RT_F_NO_FRESNEL 4u  /* dielectric always refracts unless total reflection (raytracer.cpp:1033) */
+#define RT_F_NO_JITTER 8u   /* camera ray Ray(C,u) through the pixel centre (raytracer.cpp:1482), no RNG draws */
+#define RT_F_COUNTERS 16u   /* accumulate rt_counters (slower) */
+
+typedef struct rt_params {
+    int32_t W, H;
+    int32_t spp;        /* samples rendered by this call, per pixel */
+    int32_t spp_offset; /* global index of the first of them (spp sharding) */
+    uint64_t seed;      /* RNG key; the reference seeds its engine with 10 (raytracer.cpp:26) */
+    uint32_t flags;
+    int32_t max_rebond;   /* 10: paths stop when rebond > max_rebond (raytracer.cpp:962) */
+    double ior;           /* 1.4  (raytracer.cpp:984) */
+    double epsilon;       /* 1e-5 (raytracer.cpp:955) */
+    double shadow_bias;   /* 1e-4 (raytracer.cpp:1073) */
+    int32_t rect[4];      /* j0, i0, j1, i1: render pixels j0<=j<j1, i0<=i<i1; all 0 = full frame */
+} rt_params;
+
+typedef struct rt_counters {
+    uint64_t paths;      /* camera samples = Scene::getColor(r,0,false) calls (raytracer.cpp:1485) */
+    uint64_t rays;       /* Scene::intersect calls (raytracer.cpp:930) */
+    uint64_t box_tests;  /* BoudingBox::intersect calls (raytracer.cpp:163) */
+    uint64_t nodes;      /* BVH records popped (inner Noeuds visited) */
+    uint64_t tris;       /* triangle tests (raytracer.cpp:670-687) */
+    uint64_t mesh_calls; /* TriangleMesh::intersect calls that passed the root box */
+} rt_counters;
+
+typedef struct rt_ctx rt_ctx;
+
+/* Create a context on HIP device `device` (its own stream). */
+int rt_create(int device, rt_ctx **out);
+void rt_destroy(rt_ctx *ctx);
+/* Message of the last failed call on ctx (or of the last failed rt_create when ctx is NULL). */
+const char *rt_last_error(const rt_ctx *ctx);
+
+/* Replaces scene construction + the objects vector of main()
+ * (raytracer.cpp:1163-1435): copies the flattened scene to HBM. objects[0]
+ * must be a sphere unless every render uses RT_F_POINT_LIGHT: the reference
+ * dynamic_casts it unchecked (raytracer.cpp:970, :1062). */
+int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *scene);
+
+/* Replaces the pixel loop body raytracer.cpp:1457-1486 for p.spp samples of
+ * every pixel of p.rect: adds the radiance of sample k (k = spp_offset ..
+ * spp_offset+spp-1, in that order) into accum[(i*W + j)*3 + c], i = the
+ * reference's row index (not flipped).  accum is a DEVICE pointer to
+ * W*H*3 doubles, or NULL for the context's own accumulator. Asynchronous on
+ * the context's stream; rt_sync waits. */
+int rt_render(rt_ctx *ctx, const rt_camera *cam, const rt_params *p, double *accum);
+int rt_sync(rt_ctx *ctx);
+/* Zero / read back the context's own accumulator (W*H*3 doubles). */
+int rt_accum_clear(rt_ctx *ctx, int32_t W, int32_t H);
+int rt_accum_download(rt_ctx *ctx, double *host_out, int64_t n_doubles);
+/* Device address of the context's own accumulator (NULL before rt_accum_clear). */
+double *rt_accum_device_ptr(rt_ctx *ctx);
+
+/* Replaces raytracer.cpp:1488-1501: colour/spp_total, pow(.,0.45), min(255,.),
+ * truncation to unsigned char, vertical flip. accum = DEVICE pointer or NULL
+ * (own accumulator); rgb8_host receives W*H*3 bytes. Synchronous. */
+int rt_resolve(rt_ctx *ctx, const double *accum, int32_t W, int32_t H, double spp_total,
+               uint8_t *rgb8_host);
+
+/* Parity probe = Scene::intersect (raytracer.cpp:930-951) on caller-supplied
+ * rays. rays = n * 6 doubles (origin xyz, direction xyz), HOST pointer.
+ * Outputs (HOST pointers, each may be NULL): obj_id = objectId or -1 on a
+ * miss; tri_id = orig_id of the hit triangle or -1 for spheres/misses;
+ * t = hit parameter (1e10 on a miss, as the reference initialises it);
+ * PN = n*6 doubles: P then N as Scene::intersect returns them;
+ * albedo = n*3 doubles. Synchronous. */
+int rt_intersect_rays(rt_ctx *ctx, const double *rays, int64_t n, int32_t *obj_id,
+                      int32_t *tri_id, double *t, double *PN, double *albedo);
+
+/* Per-path radiance probe: radiance of the single sample (i, j, k) exactly as
+ * rt_render would add it. out = n*3 doubles (HOST); ijk = n*3 int32 (HOST). */
+int rt_sample_radiance(rt_ctx *ctx, const rt_camera *cam, const rt_params *p, const int32_t *ijk,
+                       int64_t n, double *out);
+
+/* Counters accumulated by renders with RT_F_COUNTERS since the last reset. */
+int rt_get_counters(rt_ctx *ctx, rt_counters *out);
+int rt_reset_counters(rt_ctx *ctx);
+
+/* Duration in milliseconds of the render kernels launched by the LAST
+ * rt_render call, measured with HIP events on the context's stream; waits
+ * for them. n_launches (may be NULL) receives how many kernels that was. */
+int rt_last_render_ms(rt_ctx *ctx, double *ms, int32_t *n_launches);
+
+/* The HIP stream of the context as a void* (hipStream_t), for callers that
+ * want to order their own work after a render. */
+void *rt_stream(rt_ctx *ctx);
+
+/* Library version / build info string. */
+const char *rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

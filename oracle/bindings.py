@@ -1,0 +1,284 @@
+"""ctypes bindings of the CPU oracle (oracle/libref_cpu.so) and, where it was built, of the real
+reference classes (oracle/_ref/libref_true.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg. The product (ray-tracing_amd/) never imports this module.
+
+Scenes are given as the plain-data object list of `scenes.export_objects` (dicts with final arrays),
+so the checkers see exactly the geometry the GPU path sees, without sharing any of its code.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_LIB = os.path.join(_HERE, "libref_cpu.so")
+TRUEREF_LIB = os.path.join(_HERE, "_ref", "libref_true.so")
+
+_vp, _i32, _i64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+_pd = C.POINTER(C.c_double)
+
+
+def build(quiet=True):
+    """(re)build the oracle and, where /root/reference exists, oracle/_ref"""
+    subprocess.check_call(["make", "-C", _HERE] + (["-s"] if quiet else []))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_vp) if a is not None else None
+
+
+def _d3(v):
+    return (C.c_double * 3)(*[float(x) for x in v])
+
+
+def _load_oracle():
+    if not os.path.exists(ORACLE_LIB):
+        build()
+    lib = C.CDLL(ORACLE_LIB)
+    lib.orc_scene_create.restype = _vp
+    lib.orc_scene_create.argtypes = [_dbl, _pd]
+    lib.orc_scene_destroy.argtypes = [_vp]
+    lib.orc_add_sphere.argtypes = [_vp, _pd, _dbl, _pd, C.c_int, C.c_int]
+    lib.orc_add_mesh.argtypes = [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _pd, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]
+    lib.orc_mesh_bvh_info.argtypes = [_vp, C.c_int, _vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i32)]
+    lib.orc_mesh_bvh_dump.restype = _i64
+    lib.orc_mesh_bvh_dump.argtypes = [_vp, C.c_int, _vp, _vp, _i64]
+    lib.orc_intersect_rays.argtypes = [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]
+    lib.orc_sample_radiance.argtypes = [_vp, _vp, _vp, _vp, _i64, _vp]
+    lib.orc_render.argtypes = [_vp, _vp, _vp, _vp, C.c_int, _vp]
+    lib.orc_resolve.argtypes = [_vp, _i32, _i32, _dbl, _vp]
+    lib.orc_rng_key.restype = C.c_uint64
+    lib.orc_rng_key.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+    lib.orc_rng_draw.restype = C.c_uint64
+    lib.orc_rng_draw.argtypes = [C.c_uint64, C.c_uint32]
+    lib.orc_rng_uniform.restype = _dbl
+    lib.orc_rng_uniform.argtypes = [C.c_uint64, C.c_uint32]
+    lib.orc_max_threads.restype = C.c_int
+    return lib
+
+
+def _load_trueref():
+    if not os.path.exists(TRUEREF_LIB):
+        return None
+    lib = C.CDLL(TRUEREF_LIB)
+    lib.trf_scene_create.restype = _vp
+    lib.trf_scene_create.argtypes = [_dbl, _pd]
+    lib.trf_scene_destroy.argtypes = [_vp]
+    lib.trf_add_sphere.argtypes = [_vp, _pd, _dbl, _pd, C.c_int, C.c_int]
+    lib.trf_add_mesh.argtypes = [_vp, _pd, C.c_int, C.c_int]
+    lib.trf_mesh_read_obj.argtypes = [_vp, C.c_int, C.c_char_p]
+    lib.trf_mesh_load_texture.argtypes = [_vp, C.c_int, C.c_char_p]
+    lib.trf_mesh_add_texture_raw.argtypes = [_vp, C.c_int, _vp, C.c_int, C.c_int]
+    lib.trf_mesh_set_raw.argtypes = [_vp, C.c_int, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]
+    lib.trf_mesh_op.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _dbl]
+    lib.trf_mesh_build_bvh.argtypes = [_vp, C.c_int]
+    lib.trf_mesh_sizes.argtypes = [_vp, C.c_int, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32)]
+    lib.trf_mesh_get.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp]
+    lib.trf_mesh_texture.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(_i32), C.POINTER(_i32), _vp]
+    lib.trf_bvh_dump.restype = _i64
+    lib.trf_bvh_dump.argtypes = [_vp, C.c_int, _vp, _vp, _i64]
+    lib.trf_intersect_rays.argtypes = [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]
+    lib.trf_sample_radiance.argtypes = [_vp, _vp, _vp, _vp, _i64, _vp]
+    lib.trf_render.argtypes = [_vp, _vp, _vp, _vp]
+    lib.trf_resolve.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp]
+    lib.trf_camera_basis.argtypes = [_dbl, _dbl, _dbl, C.c_int, _pd, _pd, _pd, _pd]
+    lib.trf_draws.restype = C.c_uint64
+    return lib
+
+
+orc = _load_oracle()
+trf = _load_trueref()
+
+
+def have_trueref():
+    return trf is not None
+
+
+def _hit_arrays(n):
+    return (np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n), np.empty((n, 6)), np.empty((n, 3)))
+
+
+class OracleScene:
+    """The CPU restatement (oracle/ref_cpu.cpp) on an exported object list."""
+
+    def __init__(self, objects, I, L):
+        self._keep = []
+        self._h = orc.orc_scene_create(float(I), _d3(L))
+        self.mesh_ids = []
+        for o in objects:
+            if o["kind"] == "sphere":
+                orc.orc_add_sphere(self._h, _d3(o["O"]), float(o["R"]), _d3(o["albedo"]), int(o["mirror"]), int(o["transp"]))
+            else:
+                v = np.ascontiguousarray(o["verts"], np.float64)
+                n = np.ascontiguousarray(o["normals"], np.float64)
+                uv = np.ascontiguousarray(o["uvs"], np.float64)
+                ix = np.ascontiguousarray(o["idx"], np.int32)
+                texs = [np.ascontiguousarray(t, np.uint8) for t in o.get("textures", [])]
+                self._keep += texs
+                nt = len(texs)
+                tp = (_vp * max(nt, 1))(*[t.ctypes.data for t in texs])
+                tw = (_i32 * max(nt, 1))(*[t.shape[1] for t in texs])
+                th = (_i32 * max(nt, 1))(*[t.shape[0] for t in texs])
+                oid = orc.orc_add_mesh(self._h, len(v), _ptr(v), len(n), _ptr(n), len(uv), _ptr(uv), len(ix), _ptr(ix), _d3(o["albedo"]),
+                                       int(o["mirror"]), int(o["transp"]), nt, tp, tw, th)
+                self.mesh_ids.append(oid)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            orc.orc_scene_destroy(self._h)
+            self._h = None
+
+    def intersect_rays(self, rays, counters=None):
+        rays = np.ascontiguousarray(rays, np.float64).reshape(-1, 6)
+        obj, tri, t, PN, alb = _hit_arrays(len(rays))
+        orc.orc_intersect_rays(self._h, _ptr(rays), len(rays), _ptr(obj), _ptr(tri), _ptr(t), _ptr(PN), _ptr(alb),
+                               C.byref(counters) if counters is not None else None)
+        return dict(obj=obj, tri=tri, t=t, P=PN[:, :3].copy(), N=PN[:, 3:].copy(), albedo=alb)
+
+    def sample_radiance(self, cam, params, ijk):
+        ijk = np.ascontiguousarray(ijk, np.int32).reshape(-1, 3)
+        out = np.empty((len(ijk), 3))
+        orc.orc_sample_radiance(self._h, C.byref(cam), C.byref(params), _ptr(ijk), len(ijk), _ptr(out))
+        return out
+
+    def render(self, cam, params, accum=None, n_threads=0, counters=None):
+        if accum is None:
+            accum = np.zeros((params.H, params.W, 3))
+        orc.orc_render(self._h, C.byref(cam), C.byref(params), _ptr(accum), int(n_threads),
+                       C.byref(counters) if counters is not None else None)
+        return accum
+
+    def bvh_info(self, object_id, n_tris):
+        perm = np.empty(n_tris, np.int32)
+        nn, nl, md, ml = _i64(), _i64(), _i32(), _i32()
+        rc = orc.orc_mesh_bvh_info(self._h, object_id, _ptr(perm), C.byref(nn), C.byref(nl), C.byref(md), C.byref(ml))
+        assert rc == 0
+        return dict(perm=perm, n_nodes=nn.value, n_leaves=nl.value, max_depth=md.value, max_leaf=ml.value)
+
+    def bvh_dump(self, object_id, n_nodes):
+        boxes = np.empty((n_nodes, 6)); dfl = np.empty((n_nodes, 3), np.int32)
+        k = orc.orc_mesh_bvh_dump(self._h, object_id, _ptr(boxes), _ptr(dfl), n_nodes)
+        assert k == n_nodes, (k, n_nodes)
+        return boxes, dfl
+
+
+def resolve(accum, spp_total):
+    accum = np.ascontiguousarray(accum, np.float64)
+    H, W, _ = accum.shape
+    out = np.empty((H, W, 3), np.uint8)
+    orc.orc_resolve(_ptr(accum), W, H, float(spp_total), _ptr(out))
+    return out
+
+
+class TrueRefScene:
+    """The reference's own Scene / Sphere / TriangleMesh objects (oracle/_ref)."""
+
+    def __init__(self, objects, I, L, build_bvh=True):
+        assert trf is not None, "oracle/_ref not built (needs /root/reference)"
+        self._h = trf.trf_scene_create(float(I), _d3(L))
+        self.mesh_ids = []
+        for o in objects:
+            if o["kind"] == "sphere":
+                trf.trf_add_sphere(self._h, _d3(o["O"]), float(o["R"]), _d3(o["albedo"]), int(o["mirror"]), int(o["transp"]))
+            else:
+                oid = trf.trf_add_mesh(self._h, _d3(o["albedo"]), int(o["mirror"]), int(o["transp"]))
+                self.mesh_ids.append(oid)
+                if "obj_path" in o:
+                    assert trf.trf_mesh_read_obj(self._h, oid, os.fsencode(o["obj_path"])) == 0
+                else:
+                    v = np.ascontiguousarray(o["verts"], np.float64)
+                    n = np.ascontiguousarray(o["normals"], np.float64)
+                    uv = np.ascontiguousarray(o["uvs"], np.float64)
+                    ix = np.ascontiguousarray(o["idx"], np.int32)
+                    trf.trf_mesh_set_raw(self._h, oid, len(v), _ptr(v), len(n), _ptr(n), len(uv), _ptr(uv), len(ix), _ptr(ix))
+                for t in o.get("textures", []):
+                    t = np.ascontiguousarray(t, np.uint8)
+                    trf.trf_mesh_add_texture_raw(self._h, oid, _ptr(t), t.shape[1], t.shape[0])
+                for p in o.get("texture_paths", []):
+                    assert trf.trf_mesh_load_texture(self._h, oid, os.fsencode(p)) == 0
+                for op in o.get("ops", []):
+                    self.mesh_op(oid, *op)
+                if build_bvh:
+                    trf.trf_mesh_build_bvh(self._h, oid)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and trf is not None:
+            trf.trf_scene_destroy(self._h)
+            self._h = None
+
+    def mesh_op(self, oid, name, a=0, b=0, angle=0.0):
+        ops = {"invertNormals": 0, "translate": 1, "rotateNormals": 2, "rotate": 3, "rotateAroundAxe": 4, "zoom": 5}
+        if name == "rotateAroundAxe":
+            a, b, angle = a, 0, b
+        if name == "zoom":
+            a, b = 0, a
+        assert trf.trf_mesh_op(self._h, oid, ops[name], int(a), int(b), float(angle)) == 0
+
+    def build_bvh(self, oid):
+        trf.trf_mesh_build_bvh(self._h, oid)
+
+    def mesh_arrays(self, oid):
+        nv, nn, nuv, nt, ntex = _i64(), _i64(), _i64(), _i64(), _i32()
+        trf.trf_mesh_sizes(self._h, oid, C.byref(nv), C.byref(nn), C.byref(nuv), C.byref(nt), C.byref(ntex))
+        v = np.empty((nv.value, 3)); n = np.empty((nn.value, 3)); uv = np.empty((nuv.value, 2))
+        ix = np.empty((nt.value, 10), np.int32); perm = np.full(nt.value, -1, np.int32)
+        trf.trf_mesh_get(self._h, oid, _ptr(v), _ptr(n), _ptr(uv), _ptr(ix), _ptr(perm))
+        return v, n, uv, ix, perm
+
+    def mesh_texture(self, oid, k):
+        W, H = _i32(), _i32()
+        assert trf.trf_mesh_texture(self._h, oid, k, C.byref(W), C.byref(H), None) == 0
+        out = np.empty((H.value, W.value, 3), np.uint8)
+        trf.trf_mesh_texture(self._h, oid, k, C.byref(W), C.byref(H), _ptr(out))
+        return out
+
+    def bvh_dump(self, oid):
+        n = trf.trf_bvh_dump(self._h, oid, None, None, 0)
+        boxes = np.empty((n, 6)); dfl = np.empty((n, 3), np.int32)
+        trf.trf_bvh_dump(self._h, oid, _ptr(boxes), _ptr(dfl), n)
+        return boxes, dfl
+
+    def intersect_rays(self, rays):
+        rays = np.ascontiguousarray(rays, np.float64).reshape(-1, 6)
+        obj, tri, t, PN, alb = _hit_arrays(len(rays))
+        trf.trf_intersect_rays(self._h, _ptr(rays), len(rays), _ptr(obj), _ptr(tri), _ptr(t), _ptr(PN), _ptr(alb))
+        return dict(obj=obj, tri=tri, t=t, P=PN[:, :3].copy(), N=PN[:, 3:].copy(), albedo=alb)
+
+    def sample_radiance(self, cam, params, ijk):
+        ijk = np.ascontiguousarray(ijk, np.int32).reshape(-1, 3)
+        out = np.empty((len(ijk), 3))
+        assert trf.trf_sample_radiance(self._h, C.byref(cam), C.byref(params), _ptr(ijk), len(ijk), _ptr(out)) == 0
+        return out
+
+    def render(self, cam, params, accum=None):
+        if accum is None:
+            accum = np.zeros((params.H, params.W, 3))
+        assert trf.trf_render(self._h, C.byref(cam), C.byref(params), _ptr(accum)) == 0
+        return accum
+
+
+def trueref_resolve(accum, nbrays):
+    accum = np.ascontiguousarray(accum, np.float64)
+    H, W, _ = accum.shape
+    out = np.empty((H, W, 3), np.uint8)
+    trf.trf_resolve(_ptr(accum), W, H, int(nbrays), _ptr(out))
+    return out
+
+
+def primary_rays(cam, W, H, rect=None):
+    """Un-jittered camera rays Ray(C, u) through pixel centres (raytracer.cpp:1475-1477, :1482),
+    computed with exactly-rounded operations only; returns (rays (n,6), ij (n,2))."""
+    j0, i0, j1, i1 = rect if rect else (0, 0, W, H)
+    ii, jj = np.meshgrid(np.arange(i0, i1), np.arange(j0, j1), indexing="ij")
+    x = (jj - W // 2 + 0.5).astype(np.float64).ravel()
+    y = (ii - H // 2 + 0.5).astype(np.float64).ravel()
+    z = np.full_like(x, cam.zdist)
+    n = np.sqrt(x * x + y * y + z * z)
+    x, y, z = x / n, y / n, z / n
+    r, u, v = np.array(cam.right[:]), np.array(cam.up[:]), np.array(cam.view[:])
+    d = (x[:, None] * r[None, :] + y[:, None] * u[None, :]) + z[:, None] * v[None, :]
+    rays = np.concatenate([np.broadcast_to(np.array(cam.C[:]), d.shape), d], 1)
+    return np.ascontiguousarray(rays), np.stack([ii.ravel(), jj.ravel()], 1)

@@ -1,0 +1,711 @@
+/*
+ * ref_cpu.cpp - CPU oracle (see ref_cpu.h: test infrastructure only).
+ *
+ * Clean-room FP64 restatement of the hot path of /root/reference/raytracer.cpp.
+ * Every function cites the lines it follows. Operation ORDER follows the
+ * reference expression by expression, so that with the same libm and without
+ * FMA contraction (build with -ffp-contract=off) results are bit-identical to
+ * the reference's own classes driven with the same random numbers.
+ *
+ * The one deliberate change is the random source (raytracer.cpp:26-27): the
+ * global minstd engine is replaced by a counter-based stream keyed by
+ * (seed, pixel, sample); draw n of a path is a pure function of (key, n).
+ * Draw order along a path is the reference's: camera u1..u4 (:1467-1471),
+ * then per vertex 1 draw for the dielectric coin (:1006) or 2+2 for the two
+ * random_cos calls of a diffuse vertex (:1061, :1086).
+ */
+#include "ref_cpu.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+const double kPi = 3.14159265358979323846; /* raytracer.cpp:15 */
+
+/* ---- 3-vector algebra: raytracer.cpp:29-110 -------------------------------------------- */
+struct V3 {
+    double x, y, z;
+};
+inline V3 mk(double x, double y, double z) { return V3{x, y, z}; }
+inline V3 add(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }    /* :62 */
+inline V3 sub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }    /* :67 */
+inline V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }                        /* :72 */
+inline V3 smul(double s, V3 b) { return mk(s * b.x, s * b.y, s * b.z); }     /* :77 */
+inline V3 muls(V3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }     /* :82 */
+inline V3 cmul(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }   /* :87 */
+inline V3 divs(V3 a, double s) { return mk(a.x / s, a.y / s, a.z / s); }     /* :92 */
+inline V3 cross(V3 a, V3 b) {                                               /* :97 */
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; } /* :102 */
+inline double sqr(double v) { return v * v; }                               /* :107 */
+inline double norm2(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }     /* :40 */
+inline V3 unit(V3 a) {                                                      /* :44-48, no zero guard */
+    double n = sqrt(norm2(a));
+    return mk(a.x / n, a.y / n, a.z / n);
+}
+/* std::min / std::max as libstdc++ defines them: the FIRST argument comes back unless the
+ * comparison says otherwise, so a NaN second argument is dropped and a NaN first one kept. */
+inline double smin(double a, double b) { return (b < a) ? b : a; }
+inline double smax(double a, double b) { return (a < b) ? b : a; }
+inline double comp(const V3 &v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
+
+/* ---- counter-based random stream (replaces raytracer.cpp:26-27) ------------------------- */
+inline uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+inline uint64_t rng_key(uint64_t seed, uint32_t pixel, uint32_t sample) {
+    return mix64(mix64(seed + 0x9E3779B97F4A7C15ull) + (((uint64_t)pixel << 32) | (uint64_t)sample));
+}
+inline uint64_t rng_draw(uint64_t key, uint32_t n) {
+    return mix64(key + ((uint64_t)n + 1ull) * 0x9E3779B97F4A7C15ull);
+}
+struct Rng {
+    uint64_t key;
+    uint32_t n;
+    double uniform() { /* 53 random bits in [0,1) */
+        return (double)(rng_draw(key, n++) >> 11) * (1.0 / 9007199254740992.0);
+    }
+    int rand31() { return (int)(rng_draw(key, n++) >> 33); } /* stands in for rand(), :1006 */
+};
+
+/* ---- scene data ------------------------------------------------------------------------- */
+struct Box {
+    V3 lo, hi;
+};
+struct TriIdx { /* raytracer.cpp:198-206, member order */
+    int vi, vj, vk, ti, tj, tk, ni, nj, nk, group;
+};
+struct Node { /* raytracer.cpp:190-196 with indices for pointers */
+    int left, right; /* -1 on a leaf */
+    Box b;
+    int debut, fin;
+};
+struct Mesh {
+    std::vector<V3> verts, normals, uvs;
+    std::vector<TriIdx> idx;
+    std::vector<int> orig; /* orig[k] = face-fan index of the triangle now at position k */
+    std::vector<const uint8_t *> tex;
+    std::vector<int> texW, texH;
+    std::vector<Node> nodes; /* nodes[0] = root */
+};
+struct Obj {
+    int kind; /* 0 sphere, 1 mesh */
+    V3 albedo;
+    bool mirror, transp;
+    V3 O;
+    double R;
+    Mesh *mesh;
+};
+struct Cnt {
+    uint64_t paths, rays, box_tests, nodes, tris, mesh_calls;
+};
+
+} // namespace
+
+struct orc_scene {
+    std::vector<Obj> objects;
+    V3 L;
+    double I;
+    double lut[256];
+};
+
+namespace {
+
+struct Ray {
+    V3 C, u;
+};
+
+/* BoudingBox::intersect, raytracer.cpp:163-186 */
+inline bool box_hit(const Box &b, const Ray &r) {
+    double t1x = (b.lo.x - r.C.x) / r.u.x, t2x = (b.hi.x - r.C.x) / r.u.x;
+    double txMin = smin(t1x, t2x), txMax = smax(t1x, t2x);
+    double t1y = (b.lo.y - r.C.y) / r.u.y, t2y = (b.hi.y - r.C.y) / r.u.y;
+    double tyMin = smin(t1y, t2y), tyMax = smax(t1y, t2y);
+    double t1z = (b.lo.z - r.C.z) / r.u.z, t2z = (b.hi.z - r.C.z) / r.u.z;
+    double tzMin = smin(t1z, t2z), tzMax = smax(t1z, t2z);
+    double tMax = smin(txMax, smin(tyMax, tzMax));
+    double tMin = smax(txMin, smax(tyMin, tzMin));
+    if (tMax < 0) return false;
+    return tMax > tMin;
+}
+
+/* TriangleMesh::buildBB, raytracer.cpp:220-242 */
+Box build_bb(const Mesh &m, int debut, int fin) {
+    Box bb;
+    bb.lo = mk(1E9, 1E9, 1E9);
+    bb.hi = mk(-1E9, -1E9, -1E9);
+    for (int i = debut; i < fin; i++) {
+        const V3 *p[3] = {&m.verts[m.idx[i].vi], &m.verts[m.idx[i].vj], &m.verts[m.idx[i].vk]};
+        for (int k = 0; k < 3; k++) {
+            bb.lo.x = smin(bb.lo.x, p[k]->x); bb.hi.x = smax(bb.hi.x, p[k]->x);
+            bb.lo.y = smin(bb.lo.y, p[k]->y); bb.hi.y = smax(bb.hi.y, p[k]->y);
+            bb.lo.z = smin(bb.lo.z, p[k]->z); bb.hi.z = smax(bb.hi.z, p[k]->z);
+        }
+    }
+    return bb;
+}
+
+/* TriangleMesh::buildBVH, raytracer.cpp:244-291 */
+void build_bvh(Mesh &m, int node, int debut, int fin) {
+    m.nodes[node].debut = debut;
+    m.nodes[node].fin = fin;
+    m.nodes[node].b = build_bb(m, debut, fin);
+    V3 diag = sub(m.nodes[node].b.hi, m.nodes[node].b.lo);
+    int dim;
+    if (diag.x >= diag.y && diag.x >= diag.z) dim = 0;
+    else if (diag.y >= diag.x && diag.y >= diag.z) dim = 1;
+    else dim = 2;
+    double milieu = (comp(m.nodes[node].b.lo, dim) + comp(m.nodes[node].b.hi, dim)) * 0.5;
+    int pivot = debut;
+    for (int i = debut; i < fin; i++) {
+        double c = (comp(m.verts[m.idx[i].vi], dim) + comp(m.verts[m.idx[i].vj], dim) +
+                    comp(m.verts[m.idx[i].vk], dim)) / 3;
+        if (c < milieu) {
+            TriIdx ti = m.idx[i]; m.idx[i] = m.idx[pivot]; m.idx[pivot] = ti;
+            int oi = m.orig[i]; m.orig[i] = m.orig[pivot]; m.orig[pivot] = oi;
+            pivot++;
+        }
+    }
+    m.nodes[node].left = -1;
+    m.nodes[node].right = -1;
+    if (pivot == debut || pivot == fin || fin - debut < 5) return;
+    int l = (int)m.nodes.size();
+    m.nodes.push_back(Node());
+    int r = (int)m.nodes.size();
+    m.nodes.push_back(Node());
+    m.nodes[node].left = l;
+    m.nodes[node].right = r;
+    build_bvh(m, l, debut, pivot);
+    build_bvh(m, r, pivot, fin);
+}
+
+struct MeshHit {
+    V3 P, N, color;
+    double t;
+    int tri;
+};
+
+/* TriangleMesh::intersect, raytracer.cpp:642-757 */
+bool mesh_hit(const orc_scene &sc, const Obj &o, const Ray &r, MeshHit &h, Cnt *cnt) {
+    const Mesh &m = *o.mesh;
+    if (cnt) cnt->box_tests++;
+    if (!box_hit(m.nodes[0].b, r)) return false; /* :644 */
+    if (cnt) cnt->mesh_calls++;
+    h.t = 1E9;
+    h.tri = -1;
+    bool has_inter = false;
+    /* the std::list used as a LIFO: push_front / pop_front (:650-665) */
+    std::vector<int> stack;
+    stack.push_back(0);
+    while (!stack.empty()) {
+        int c = stack.back();
+        stack.pop_back();
+        const Node &nd = m.nodes[c];
+        if (nd.left >= 0) {
+            if (cnt) { cnt->nodes++; cnt->box_tests += 2; }
+            if (box_hit(m.nodes[nd.left].b, r)) stack.push_back(nd.left);
+            if (box_hit(m.nodes[nd.right].b, r)) stack.push_back(nd.right); /* popped first */
+        } else {
+            for (int i = nd.debut; i < nd.fin; i++) {
+                if (cnt) cnt->tris++;
+                const TriIdx &ti = m.idx[i];
+                const V3 &A = m.verts[ti.vi], &B = m.verts[ti.vj], &C = m.verts[ti.vk];
+                V3 e1 = sub(B, A), e2 = sub(C, A), N = cross(e1, e2), AO = sub(r.C, A),
+                   AOu = cross(AO, r.u);
+                double invUN = 1. / dot(r.u, N);
+                double beta = -dot(e2, AOu) * invUN, gamma = dot(e1, AOu) * invUN,
+                       alpha = 1 - beta - gamma, localt = -dot(AO, N) * invUN;
+                if (beta >= 0 && gamma >= 0 && beta <= 1 && gamma <= 1 && alpha >= 0 && localt > 0) {
+                    has_inter = true;
+                    if (localt < h.t) {
+                        h.t = localt;
+                        h.tri = m.orig[i];
+                        V3 nn = add(add(smul(alpha, m.normals[ti.ni]), smul(beta, m.normals[ti.nj])),
+                                    smul(gamma, m.normals[ti.nk]));
+                        h.N = unit(nn);
+                        h.P = add(r.C, r.u); /* :696, sic */
+                        if (m.tex.size() > 0) {
+                            int H = m.texH[ti.group], W = m.texW[ti.group];
+                            V3 UV = add(add(smul(alpha, m.uvs[ti.ti]), smul(beta, m.uvs[ti.tj])),
+                                        smul(gamma, m.uvs[ti.tk]));
+                            UV = cmul(UV, mk(W, H, 0));
+                            int uvx = (int)(UV.x + 0.5);
+                            int uvy = (int)(UV.y + 0.5);
+                            uvx = uvx % W;
+                            uvy = uvy % H;
+                            if (uvx < 0) uvx += W;
+                            if (uvy < 0) uvy += H;
+                            uvy = H - uvy - 1;
+                            const uint8_t *tx = m.tex[ti.group];
+                            h.color = mk(sc.lut[tx[(uvy * W + uvx) * 3]], sc.lut[tx[(uvy * W + uvx) * 3 + 1]],
+                                         sc.lut[tx[(uvy * W + uvx) * 3 + 2]]);
+                        } else {
+                            h.color = o.albedo;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    return has_inter;
+}
+
+struct SceneHit {
+    V3 P, N, albedo;
+    bool mirror, transp;
+    double t;
+    int objectId, tri;
+};
+
+/* Sphere::intersect, raytracer.cpp:883-918 */
+inline bool sphere_hit(const Obj &s, const Ray &r, V3 &P, V3 &N, double &t) {
+    double a = 1;
+    double b = 2 * dot(r.u, sub(r.C, s.O));
+    double c = norm2(sub(r.C, s.O)) - s.R * s.R;
+    double delta = b * b - 4 * a * c;
+    if (delta < 0) return false;
+    double sqDelta = sqrt(delta);
+    double t2 = (-b + sqDelta) / (2 * a);
+    if (t2 < 0) return false;
+    double t1 = (-b - sqDelta) / (2 * a);
+    if (t1 > 0) t = t1;
+    else t = t2;
+    P = add(r.C, smul(t, r.u));
+    N = unit(sub(P, s.O));
+    return true;
+}
+
+/* Scene::intersect, raytracer.cpp:930-951 */
+bool scene_hit(const orc_scene &sc, const Ray &r, SceneHit &h, Cnt *cnt) {
+    if (cnt) cnt->rays++;
+    h.t = 1E10;
+    h.objectId = -1;
+    h.tri = -1;
+    bool has_inter = false;
+    for (size_t i = 0; i < sc.objects.size(); i++) {
+        const Obj &o = sc.objects[i];
+        V3 lP, lN, lA;
+        double lt;
+        int ltri = -1;
+        bool ok;
+        if (o.kind == 0) {
+            lA = o.albedo; /* :890, written before the reject */
+            ok = sphere_hit(o, r, lP, lN, lt);
+        } else {
+            MeshHit mh;
+            mh.P = mh.N = mh.color = mk(0, 0, 0);
+            mh.t = 0;
+            mh.tri = -1;
+            ok = mesh_hit(sc, o, r, mh, cnt);
+            if (ok) { lP = mh.P; lN = mh.N; lA = mh.color; lt = mh.t; ltri = mh.tri; }
+        }
+        if (ok && lt < h.t) {
+            h.t = lt;
+            has_inter = true;
+            h.albedo = lA;
+            h.P = lP;
+            h.N = lN;
+            h.mirror = o.mirror;
+            h.transp = o.transp;
+            h.objectId = (int)i;
+            h.tri = ltri;
+        }
+    }
+    return has_inter;
+}
+
+/* random_cos, raytracer.cpp:112-138 */
+V3 random_cos(Rng &g, V3 N) {
+    double u1 = g.uniform();
+    double u2 = g.uniform();
+    double x = cos(2 * kPi * u1) * sqrt(1 - u2);
+    double y = sin(2 * kPi * u1) * sqrt(1 - u2);
+    double z = sqrt(u2);
+    V3 T1;
+    if (N.x < N.y && N.x < N.z) T1 = mk(0, N.z, -N.y);
+    else if (N.y < N.z && N.y < N.x) T1 = mk(N.z, 0, -N.x);
+    else T1 = mk(N.y, -N.x, 0);
+    T1 = unit(T1);
+    V3 T2 = cross(N, T1);
+    return add(add(smul(z, N), smul(x, T1)), smul(y, T2));
+}
+
+struct Ctx {
+    const orc_scene *sc;
+    const rt_params *p;
+    Cnt *cnt;
+};
+
+/* Scene::getColor, raytracer.cpp:953-1093 (+ the commented variants behind flags) */
+V3 get_color(const Ctx &cx, Rng &g, const Ray &r, int rebond, bool lastDiffuse) {
+    const orc_scene &sc = *cx.sc;
+    const uint32_t fl = cx.p->flags;
+    double epsilon = cx.p->epsilon;
+    SceneHit h;
+    bool inter = scene_hit(sc, r, h, cx.cnt); /* before the depth test, :960-963 */
+    V3 color = mk(0, 0, 0);
+    if (rebond > cx.p->max_rebond) return mk(0., 0., 0.);
+    if (!inter) return color;
+    const V3 P = h.P, N = h.N, albedo = h.albedo;
+    if (h.objectId == 0 && !(fl & RT_F_POINT_LIGHT)) { /* :966-973 */
+        if (rebond == 0 || !lastDiffuse) {
+            double Rl = sc.objects[0].R;
+            return divs(mk(sc.I, sc.I, sc.I), 4 * kPi * kPi * sqr(Rl));
+        }
+        return mk(0., 0., 0.);
+    }
+    if (h.mirror) { /* :974-979 */
+        V3 reflectedDir = sub(r.u, smul(2 * dot(r.u, N), N));
+        Ray rr{add(P, smul(epsilon, N)), reflectedDir};
+        return get_color(cx, g, rr, rebond + 1, false);
+    }
+    if (h.transp) { /* :982-1021 */
+        double n1 = 1, n2 = cx.p->ior;
+        V3 N2 = N;
+        if (dot(r.u, N) > 0) {
+            double tmp = n1; n1 = n2; n2 = tmp;
+            N2 = neg(N);
+        }
+        double rad = 1 - sqr(n1 / n2) * (1 - sqr(dot(r.u, N2)));
+        if (rad < 0) {
+            V3 reflectedDir = sub(r.u, smul(2 * dot(r.u, N), N));
+            Ray rr{add(P, smul(epsilon, N)), reflectedDir};
+            return get_color(cx, g, rr, rebond + 1, false);
+        }
+        bool reflect = false;
+        if (!(fl & RT_F_NO_FRESNEL)) {
+            double k0 = sqr(n1 - n2) / sqr(n1 + n2);
+            double R = k0 + (1 - k0) * sqr(sqr(1 - fabs(dot(N2, r.u)))) * (1 - fabs(dot(N2, r.u)));
+            double random = g.rand31() % 100;
+            reflect = (random <= 100 * R);
+        }
+        if (reflect) {
+            V3 reflectedDir = sub(r.u, smul(2 * dot(r.u, N), N));
+            Ray rr{add(P, smul(epsilon, N)), reflectedDir}; /* N, not N2: :1011 */
+            return get_color(cx, g, rr, rebond + 1, false);
+        }
+        V3 tT = smul(n1 / n2, sub(r.u, smul(dot(r.u, N2), N2)));
+        V3 tN = smul(-sqrt(rad), N2);
+        V3 refractedDir = add(tT, tN);
+        Ray rr{sub(P, smul(epsilon, N2)), refractedDir};
+        return get_color(cx, g, rr, rebond + 1, false);
+    }
+    /* diffuse */
+    if (fl & RT_F_POINT_LIGHT) { /* :1040-1055 */
+        V3 PL = sub(sc.L, P);
+        double d = sqrt(norm2(PL));
+        SceneHit sh;
+        Ray shadowRay{add(P, smul(0.00001, N)), divs(PL, d)};
+        bool shadowInter = scene_hit(sc, shadowRay, sh, cx.cnt);
+        if (shadowInter && sh.t < d) {
+            color = mk(0., 0., 0.);
+        } else {
+            color = muls(smul(sc.I / (4 * kPi * d * d), divs(albedo, kPi)), smax(0., dot(N, divs(PL, d))));
+        }
+    } else { /* :1059-1083 */
+        const Obj &lum = sc.objects[0];
+        V3 PL = sub(sc.L, P);
+        PL = unit(PL);
+        V3 w = random_cos(g, neg(PL));
+        V3 xprime = add(muls(w, lum.R), lum.O);
+        V3 Pxprime = sub(xprime, P);
+        double d = sqrt(norm2(Pxprime));
+        Pxprime = divs(Pxprime, d);
+        SceneHit sh;
+        Ray shadowRay{add(P, smul(0.00001, N)), Pxprime};
+        bool shadowInter = scene_hit(sc, shadowRay, sh, cx.cnt);
+        if (shadowInter && sh.t < d - cx.p->shadow_bias) {
+            color = mk(0., 0., 0.);
+        } else {
+            double R2 = sqr(lum.R);
+            double proba = smax(1E-8, dot(neg(PL), w)) / (kPi * R2);
+            double J = smax(0., dot(w, neg(Pxprime))) / (d * d);
+            color = divs(muls(muls(smul(sc.I / (4 * kPi * kPi * R2), divs(albedo, kPi)),
+                                   smax(0., dot(N, Pxprime))), J), proba);
+        }
+    }
+    if (!(fl & RT_F_NO_INDIRECT)) { /* :1086-1088 */
+        V3 wi = random_cos(g, N);
+        Ray wiRay{add(P, smul(epsilon, N)), wi};
+        color = add(color, cmul(albedo, get_color(cx, g, wiRay, rebond + 1, true)));
+    }
+    return color;
+}
+
+/* one iteration of the k loop, raytracer.cpp:1467-1485 */
+V3 sample_radiance(const Ctx &cx, const rt_camera &cam, int i, int j, int k) {
+    const rt_params &p = *cx.p;
+    Rng g;
+    g.key = rng_key(p.seed, (uint32_t)(i * p.W + j), (uint32_t)k);
+    g.n = 0;
+    V3 C = mk(cam.C[0], cam.C[1], cam.C[2]);
+    V3 right = mk(cam.right[0], cam.right[1], cam.right[2]);
+    V3 up = mk(cam.up[0], cam.up[1], cam.up[2]);
+    V3 view = mk(cam.view[0], cam.view[1], cam.view[2]);
+    if (cx.cnt) cx.cnt->paths++;
+    if (p.flags & RT_F_NO_JITTER) { /* :1482 with the un-jittered u */
+        V3 u = mk(j - p.W / 2 + 0.5, i - p.H / 2 + 0.5, cam.zdist);
+        u = unit(u);
+        u = add(add(smul(u.x, right), smul(u.y, up)), smul(u.z, view));
+        Ray r{C, u};
+        return get_color(cx, g, r, 0, false);
+    }
+    double u1 = g.uniform(), u2 = g.uniform();
+    double x1 = cam.aa_sigma * cos(2 * kPi * u1) * sqrt(-2 * log(u2)),
+           x2 = cam.aa_sigma * sin(2 * kPi * u1) * sqrt(-2 * log(u2));
+    double u3 = g.uniform(), u4 = g.uniform();
+    double x3 = cam.dof_sigma * cos(2 * kPi * u3) * sqrt(-2 * log(u4)),
+           x4 = cam.dof_sigma * sin(2 * kPi * u3) * sqrt(-2 * log(u4));
+    V3 u = mk(j - p.W / 2 + x2 + 0.5, i - p.H / 2 + x1 + 0.5, cam.zdist);
+    u = unit(u);
+    u = add(add(smul(u.x, right), smul(u.y, up)), smul(u.z, view));
+    V3 target = add(C, smul(cam.focus, u));
+    V3 Cprime = add(C, mk(x3, x4, 0));
+    V3 uprime = unit(sub(target, Cprime));
+    Ray r{Cprime, uprime};
+    return get_color(cx, g, r, 0, false);
+}
+
+void rect_of(const rt_params &p, int &j0, int &i0, int &j1, int &i1) {
+    j0 = p.rect[0]; i0 = p.rect[1]; j1 = p.rect[2]; i1 = p.rect[3];
+    if (j0 == 0 && i0 == 0 && j1 == 0 && i1 == 0) { j1 = p.W; i1 = p.H; }
+}
+
+void cnt_add(rt_counters *dst, const Cnt &c) {
+    dst->paths += c.paths; dst->rays += c.rays; dst->box_tests += c.box_tests;
+    dst->nodes += c.nodes; dst->tris += c.tris; dst->mesh_calls += c.mesh_calls;
+}
+
+} // namespace
+
+extern "C" {
+
+orc_scene *orc_scene_create(double I, const double L[3]) {
+    orc_scene *s = new orc_scene();
+    s->I = I;
+    s->L = mk(L[0], L[1], L[2]);
+    for (int i = 0; i < 256; i++) s->lut[i] = pow(i / 255., 2.2); /* :713-715 */
+    return s;
+}
+
+void orc_scene_destroy(orc_scene *s) {
+    if (!s) return;
+    for (size_t i = 0; i < s->objects.size(); i++) delete s->objects[i].mesh;
+    delete s;
+}
+
+int orc_add_sphere(orc_scene *s, const double O[3], double R, const double albedo[3], int mirror,
+                   int transp) {
+    Obj o;
+    o.kind = 0;
+    o.albedo = mk(albedo[0], albedo[1], albedo[2]);
+    o.mirror = mirror != 0;
+    o.transp = transp != 0;
+    o.O = mk(O[0], O[1], O[2]);
+    o.R = R;
+    o.mesh = NULL;
+    s->objects.push_back(o);
+    return (int)s->objects.size() - 1;
+}
+
+int orc_add_mesh(orc_scene *s, int64_t n_verts, const double *verts, int64_t n_normals,
+                 const double *normals, int64_t n_uvs, const double *uvs, int64_t n_tris,
+                 const int32_t *tri_idx, const double albedo[3], int mirror, int transp, int n_tex,
+                 const uint8_t *const *tex, const int32_t *texW, const int32_t *texH) {
+    Mesh *m = new Mesh();
+    m->verts.resize(n_verts);
+    for (int64_t i = 0; i < n_verts; i++) m->verts[i] = mk(verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]);
+    m->normals.resize(n_normals);
+    for (int64_t i = 0; i < n_normals; i++) m->normals[i] = mk(normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]);
+    m->uvs.resize(n_uvs);
+    for (int64_t i = 0; i < n_uvs; i++) m->uvs[i] = mk(uvs[2 * i], uvs[2 * i + 1], 0); /* vt reads two values, :347 */
+    m->idx.resize(n_tris);
+    m->orig.resize(n_tris);
+    for (int64_t i = 0; i < n_tris; i++) {
+        const int32_t *q = tri_idx + 10 * i;
+        m->idx[i] = TriIdx{q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9]};
+        m->orig[i] = (int)i;
+    }
+    for (int k = 0; k < n_tex; k++) {
+        m->tex.push_back(tex[k]);
+        m->texW.push_back(texW[k]);
+        m->texH.push_back(texH[k]);
+    }
+    m->nodes.reserve(2 * (size_t)n_tris + 1);
+    m->nodes.push_back(Node());
+    build_bvh(*m, 0, 0, (int)n_tris); /* buildBVH(BVH, 0, indices.size()), :1385 */
+    Obj o;
+    o.kind = 1;
+    o.albedo = mk(albedo[0], albedo[1], albedo[2]);
+    o.mirror = mirror != 0;
+    o.transp = transp != 0;
+    o.O = mk(0, 0, 0);
+    o.R = 0;
+    o.mesh = m;
+    s->objects.push_back(o);
+    return (int)s->objects.size() - 1;
+}
+
+int orc_mesh_bvh_info(const orc_scene *s, int object_id, int32_t *perm, int64_t *n_nodes,
+                      int64_t *n_leaves, int32_t *max_depth, int32_t *max_leaf) {
+    if (object_id < 0 || object_id >= (int)s->objects.size() || s->objects[object_id].kind != 1) return -1;
+    const Mesh &m = *s->objects[object_id].mesh;
+    if (perm) for (size_t i = 0; i < m.orig.size(); i++) perm[i] = m.orig[i];
+    int64_t leaves = 0;
+    int md = 0, ml = 0;
+    std::vector<std::pair<int, int> > st;
+    st.push_back(std::make_pair(0, 0));
+    while (!st.empty()) {
+        std::pair<int, int> c = st.back();
+        st.pop_back();
+        const Node &nd = m.nodes[c.first];
+        if (nd.left < 0) {
+            leaves++;
+            if (c.second > md) md = c.second;
+            if (nd.fin - nd.debut > ml) ml = nd.fin - nd.debut;
+        } else {
+            st.push_back(std::make_pair(nd.left, c.second + 1));
+            st.push_back(std::make_pair(nd.right, c.second + 1));
+        }
+    }
+    if (n_nodes) *n_nodes = (int64_t)m.nodes.size();
+    if (n_leaves) *n_leaves = leaves;
+    if (max_depth) *max_depth = md;
+    if (max_leaf) *max_leaf = ml;
+    return 0;
+}
+
+int64_t orc_mesh_bvh_dump(const orc_scene *s, int object_id, double *boxes, int32_t *dfl,
+                          int64_t cap_nodes) {
+    if (object_id < 0 || object_id >= (int)s->objects.size() || s->objects[object_id].kind != 1) return -1;
+    const Mesh &m = *s->objects[object_id].mesh;
+    /* preorder, left before right: independent of allocation order */
+    std::vector<int> st;
+    st.push_back(0);
+    int64_t k = 0;
+    while (!st.empty()) {
+        int c = st.back();
+        st.pop_back();
+        const Node &nd = m.nodes[c];
+        if (k < cap_nodes) {
+            if (boxes) {
+                double *b = boxes + 6 * k;
+                b[0] = nd.b.lo.x; b[1] = nd.b.lo.y; b[2] = nd.b.lo.z;
+                b[3] = nd.b.hi.x; b[4] = nd.b.hi.y; b[5] = nd.b.hi.z;
+            }
+            if (dfl) { dfl[3 * k] = nd.debut; dfl[3 * k + 1] = nd.fin; dfl[3 * k + 2] = nd.left < 0; }
+        }
+        k++;
+        if (nd.left >= 0) { st.push_back(nd.right); st.push_back(nd.left); }
+    }
+    return k;
+}
+
+void orc_intersect_rays(const orc_scene *s, const double *rays, int64_t n, int32_t *obj_id,
+                        int32_t *tri_id, double *t, double *PN, double *albedo,
+                        rt_counters *counters) {
+    Cnt c;
+    memset(&c, 0, sizeof c);
+    for (int64_t q = 0; q < n; q++) {
+        Ray r{mk(rays[6 * q], rays[6 * q + 1], rays[6 * q + 2]), mk(rays[6 * q + 3], rays[6 * q + 4], rays[6 * q + 5])};
+        SceneHit h;
+        bool ok = scene_hit(*s, r, h, counters ? &c : NULL);
+        if (obj_id) obj_id[q] = ok ? h.objectId : -1;
+        if (tri_id) tri_id[q] = ok ? h.tri : -1;
+        if (t) t[q] = h.t;
+        if (PN) {
+            double *o = PN + 6 * q;
+            if (ok) { o[0] = h.P.x; o[1] = h.P.y; o[2] = h.P.z; o[3] = h.N.x; o[4] = h.N.y; o[5] = h.N.z; }
+            else for (int k = 0; k < 6; k++) o[k] = 0;
+        }
+        if (albedo) {
+            double *o = albedo + 3 * q;
+            if (ok) { o[0] = h.albedo.x; o[1] = h.albedo.y; o[2] = h.albedo.z; }
+            else for (int k = 0; k < 3; k++) o[k] = 0;
+        }
+    }
+    if (counters) cnt_add(counters, c);
+}
+
+void orc_sample_radiance(const orc_scene *s, const rt_camera *cam, const rt_params *p,
+                         const int32_t *ijk, int64_t n, double *out) {
+    Ctx cx{s, p, NULL};
+    for (int64_t q = 0; q < n; q++) {
+        V3 c = sample_radiance(cx, *cam, ijk[3 * q], ijk[3 * q + 1], ijk[3 * q + 2]);
+        out[3 * q] = c.x; out[3 * q + 1] = c.y; out[3 * q + 2] = c.z;
+    }
+}
+
+void orc_render(const orc_scene *s, const rt_camera *cam, const rt_params *p, double *accum,
+                int n_threads, rt_counters *counters) {
+    int j0, i0, j1, i1;
+    rect_of(*p, j0, i0, j1, i1);
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+#else
+    n_threads = 1;
+#endif
+    Cnt total;
+    memset(&total, 0, sizeof total);
+    /* rows in parallel, schedule(dynamic,1): raytracer.cpp:1456-1457 */
+#pragma omp parallel num_threads(n_threads)
+    {
+        Cnt c;
+        memset(&c, 0, sizeof c);
+        Ctx cx{s, p, counters ? &c : NULL};
+#pragma omp for schedule(dynamic, 1)
+        for (int i = i0; i < i1; i++) {
+            for (int j = j0; j < j1; j++) {
+                double *px = accum + ((int64_t)i * p->W + j) * 3;
+                V3 color = mk(px[0], px[1], px[2]);
+                for (int k = 0; k < p->spp; k++) /* :1464, :1485 */
+                    color = add(color, sample_radiance(cx, *cam, i, j, p->spp_offset + k));
+                px[0] = color.x; px[1] = color.y; px[2] = color.z;
+            }
+        }
+#pragma omp critical
+        {
+            total.paths += c.paths; total.rays += c.rays; total.box_tests += c.box_tests;
+            total.nodes += c.nodes; total.tris += c.tris; total.mesh_calls += c.mesh_calls;
+        }
+    }
+    if (counters) cnt_add(counters, total);
+}
+
+void orc_resolve(const double *accum, int32_t W, int32_t H, double spp_total, uint8_t *rgb8) {
+    for (int i = 0; i < H; i++)
+        for (int j = 0; j < W; j++)
+            for (int c = 0; c < 3; c++) {
+                double v = accum[((int64_t)i * W + j) * 3 + c] / spp_total;     /* :1488 */
+                rgb8[((int64_t)(H - i - 1) * W + j) * 3 + c] =
+                    (unsigned char)smin(255., pow(v, 0.45));                   /* :1499-1501 */
+            }
+}
+
+uint64_t orc_rng_key(uint64_t seed, uint32_t pixel, uint32_t sample) { return rng_key(seed, pixel, sample); }
+uint64_t orc_rng_draw(uint64_t key, uint32_t n) { return rng_draw(key, n); }
+double orc_rng_uniform(uint64_t key, uint32_t n) {
+    Rng g{key, n};
+    return g.uniform();
+}
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+} /* extern "C" */

@@ -1,0 +1,501 @@
+/*
+ * rt_capi.hip - kernels and the C ABI (include/rt_amd.h) of the gfx950 path tracer.
+ * Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see csrc/Makefile).
+ */
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "rt_amd.h"
+#include "rt_device.hip.h"
+
+using namespace rtd;
+
+#define RT_BLOCK 256
+
+/* ---------------------------------------------------------------------------------------------
+ * kernels
+ * ------------------------------------------------------------------------------------------- */
+
+/* Stage the sphere list in LDS (every ray tests every sphere: raytracer.cpp:934-938). */
+__device__ __forceinline__ const rt_sphere *stage_spheres(const DScene &sc, rt_sphere *lds) {
+    if (sc.n_spheres > RT_LDS_SPHERES_MAX) return sc.spheres;
+    const int n16 = sc.n_spheres * (int)(sizeof(rt_sphere) / 16);
+    const uint4 *src = reinterpret_cast<const uint4 *>(sc.spheres);
+    uint4 *dst = reinterpret_cast<uint4 *>(lds);
+    for (int q = threadIdx.x; q < n16; q += blockDim.x) dst[q] = src[q];
+    __syncthreads();
+    return lds;
+}
+
+/* pixel of a lane: 8x8 pixel tiles per wave so the camera rays of a wave stay together */
+__device__ __forceinline__ bool lane_pixel(const RenderArgs &ra, int &i, int &j) {
+    const int rw = ra.j1 - ra.j0, rh = ra.i1 - ra.i0;
+    const int tiles_x = (rw + 7) >> 3;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tile = gid >> 6, lane = gid & 63;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    j = ra.j0 + tx * 8 + (lane & 7);
+    i = ra.i0 + ty * 8 + (lane >> 3);
+    return (j < ra.j1) && (i < ra.i1);
+}
+
+template <bool CNT>
+__global__ void __launch_bounds__(RT_BLOCK) rt_render_kernel(DScene sc, RenderArgs ra, int k0, int nk, double *accum,
+                                                             rt_counters *counters) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const rt_sphere *sph = stage_spheres(sc, reinterpret_cast<rt_sphere *>(lds_raw));
+    int i, j;
+    const bool live = lane_pixel(ra, i, j);
+    Cnt cnt = {0, 0, 0, 0, 0, 0};
+    if (live) {
+        V3 a = trace_pixel<CNT>(sc, sph, ra, i, j, k0, nk, cnt);
+        double *px = accum + ((int64_t)i * ra.p.W + j) * 3;
+        /* one lane owns the pixel for the whole launch and launches on a stream are ordered */
+        px[0] = px[0] + a.x;
+        px[1] = px[1] + a.y;
+        px[2] = px[2] + a.z;
+    }
+    if (CNT) flush_counters(cnt, counters);
+}
+
+/* one path per thread: radiance of sample (i, j, k) */
+__global__ void __launch_bounds__(RT_BLOCK) rt_sample_kernel(DScene sc, RenderArgs ra, const int32_t *ijk, int64_t n, double *out) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const rt_sphere *sph = stage_spheres(sc, reinterpret_cast<rt_sphere *>(lds_raw));
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    Cnt cnt = {0, 0, 0, 0, 0, 0};
+    V3 a = trace_pixel<false>(sc, sph, ra, ijk[3 * q], ijk[3 * q + 1], ijk[3 * q + 2], 1, cnt);
+    out[3 * q] = a.x;
+    out[3 * q + 1] = a.y;
+    out[3 * q + 2] = a.z;
+}
+
+/* Scene::intersect probe */
+__global__ void __launch_bounds__(RT_BLOCK) rt_intersect_kernel(DScene sc, const double *rays, int64_t n, int32_t *obj_id, int32_t *tri_id,
+                                                                double *t, double *PN, double *albedo) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const rt_sphere *sph = stage_spheres(sc, reinterpret_cast<rt_sphere *>(lds_raw));
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    V3 C = ld3(rays + 6 * q), u = ld3(rays + 6 * q + 3);
+    HitRec h;
+    Cnt cnt = {0, 0, 0, 0, 0, 0};
+    bool ok = scene_closest<false>(sc, sph, C, u, h, cnt);
+    obj_id[q] = ok ? h.obj : -1;
+    tri_id[q] = (ok && h.mesh >= 0) ? sc.tris[h.prim].orig_id : -1;
+    t[q] = h.t;
+    Surf s;
+    s.P = s.N = s.albedo = mk(0, 0, 0);
+    s.flags = 0;
+    if (ok) hit_surface(sc, sph, C, u, h, s);
+    PN[6 * q] = s.P.x; PN[6 * q + 1] = s.P.y; PN[6 * q + 2] = s.P.z;
+    PN[6 * q + 3] = s.N.x; PN[6 * q + 4] = s.N.y; PN[6 * q + 5] = s.N.z;
+    albedo[3 * q] = s.albedo.x; albedo[3 * q + 1] = s.albedo.y; albedo[3 * q + 2] = s.albedo.z;
+}
+
+/* raytracer.cpp:1488-1501: /nbrays, pow 0.45, min(255, .), truncation to u8, row flip */
+__global__ void rt_resolve_kernel(const double *accum, int W, int H, double spp, uint8_t *rgb) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (int64_t)W * H) return;
+    const int i = (int)(q / W), j = (int)(q - (int64_t)i * W);
+    const double *px = accum + q * 3;
+    uint8_t *o = rgb + ((int64_t)(H - i - 1) * W + j) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        double v = px[c] / spp;
+        double g = smin(255., pow(v, 0.45));
+        o[c] = (uint8_t)(int)g; /* g is in [0,255] here: a NaN power leaves 255 (std::min keeps its first argument) */
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * host side
+ * ------------------------------------------------------------------------------------------- */
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    int last_launches = 0;
+    std::string err;
+    /* scene */
+    bool have_scene = false;
+    bool light_ok = false;
+    DScene sc{};
+    std::vector<void *> scene_allocs;
+    size_t lds_bytes = 0;
+    /* own accumulator */
+    double *accum = nullptr;
+    int accW = 0, accH = 0;
+    rt_counters *d_counters = nullptr;
+};
+
+static std::string g_create_err;
+
+static int fail(rt_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else g_create_err = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) return fail((c), RT_E_DEVICE, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+static void free_scene(rt_ctx *c) {
+    for (void *p : c->scene_allocs) (void)hipFree(p);
+    c->scene_allocs.clear();
+    c->have_scene = false;
+}
+
+template <typename T>
+static int upload_array(rt_ctx *c, const T *host, size_t n, const T **dev_out) {
+    *dev_out = nullptr;
+    if (n == 0) return RT_OK;
+    void *d = nullptr;
+    if (hipMalloc(&d, n * sizeof(T)) != hipSuccess) return fail(c, RT_E_NOMEM, "hipMalloc of %zu bytes failed", n * sizeof(T));
+    c->scene_allocs.push_back(d);
+    HIPCHK(c, hipMemcpyAsync(d, host, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    *dev_out = static_cast<const T *>(d);
+    return RT_OK;
+}
+
+extern "C" {
+
+const char *rt_version(void) { return "rt_amd 0.1 (gfx950, fp64, -ffp-contract=off)"; }
+
+int rt_create(int device, rt_ctx **out) {
+    if (!out) return fail(nullptr, RT_E_INVALID, "rt_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(nullptr, RT_E_DEVICE, "rt_create: no HIP device (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(nullptr, RT_E_INVALID, "rt_create: device %d out of range [0,%d)", device, n);
+    rt_ctx *c = new rt_ctx();
+    c->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
+        (e = hipMalloc((void **)&c->d_counters, sizeof(rt_counters))) != hipSuccess ||
+        (e = hipMemset(c->d_counters, 0, sizeof(rt_counters))) != hipSuccess) {
+        fail(nullptr, RT_E_DEVICE, "rt_create: %s", hipGetErrorString(e));
+        delete c;
+        return RT_E_DEVICE;
+    }
+    *out = c;
+    return RT_OK;
+}
+
+void rt_destroy(rt_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_scene(c);
+    if (c->accum) (void)hipFree(c->accum);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *rt_last_error(const rt_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+void *rt_stream(rt_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
+    if (!c) return RT_E_INVALID;
+    if (!s) return fail(c, RT_E_INVALID, "rt_upload_scene: scene is NULL");
+    if (s->n_spheres < 0 || s->n_meshes < 0 || s->n_nodes < 0 || s->n_tris < 0 || s->n_tex < 0)
+        return fail(c, RT_E_INVALID, "rt_upload_scene: negative count");
+    if ((s->n_spheres && !s->spheres) || (s->n_meshes && !s->meshes) || (s->n_nodes && !s->nodes) ||
+        (s->n_tris && (!s->tris || !s->attrs)) || (s->n_tex && (!s->tex || !s->texels)))
+        return fail(c, RT_E_INVALID, "rt_upload_scene: NULL array with non-zero count");
+    if (s->n_tris > 0x7fffffffLL || s->n_nodes > 0x7fffffffLL) return fail(c, RT_E_INVALID, "rt_upload_scene: more than 2^31 triangles or nodes");
+    /* validate everything the kernels index with, so a bad description is an error and not a GPU fault */
+    const int n_obj = s->n_spheres + s->n_meshes;
+    std::vector<char> seen(n_obj, 0);
+    const rt_sphere *light = nullptr;
+    for (int i = 0; i < s->n_spheres; i++) {
+        int id = s->spheres[i].object_id;
+        if (id < 0 || id >= n_obj || seen[id]) return fail(c, RT_E_INVALID, "sphere %d: object_id %d invalid or repeated", i, id);
+        seen[id] = 1;
+        if (id == 0) light = &s->spheres[i];
+    }
+    for (int mi = 0; mi < s->n_meshes; mi++) {
+        const rt_mesh &m = s->meshes[mi];
+        if (m.object_id < 0 || m.object_id >= n_obj || seen[m.object_id]) return fail(c, RT_E_INVALID, "mesh %d: object_id %d invalid or repeated", mi, m.object_id);
+        seen[m.object_id] = 1;
+        if (m.n_tris < 0 || m.first_tri < 0 || (int64_t)m.first_tri + m.n_tris > s->n_tris) return fail(c, RT_E_INVALID, "mesh %d: triangle range outside the triangle array", mi);
+        if (m.n_tex < 0 || m.first_tex < 0 || m.first_tex + m.n_tex > s->n_tex) return fail(c, RT_E_INVALID, "mesh %d: texture range outside the texture array", mi);
+        if (m.max_depth + 2 > RT_STACK_MAX) return fail(c, RT_E_INVALID, "mesh %d: BVH depth %d exceeds the traversal stack (%d)", mi, m.max_depth, RT_STACK_MAX - 2);
+        if (m.root_count < 0) return fail(c, RT_E_INVALID, "mesh %d: negative root_count", mi);
+        if (m.root_count > 0) {
+            if (m.root < m.first_tri || (int64_t)m.root + m.root_count > (int64_t)m.first_tri + m.n_tris) return fail(c, RT_E_INVALID, "mesh %d: root leaf outside its triangles", mi);
+        } else if (m.n_tris == 0) {
+            return fail(c, RT_E_INVALID, "mesh %d: empty mesh", mi);
+        } else if (m.root < 0 || m.root >= s->n_nodes) {
+            return fail(c, RT_E_INVALID, "mesh %d: root node outside the node array", mi);
+        }
+        if (m.n_tex > 0)
+            for (int32_t k = m.first_tri; k < m.first_tri + m.n_tris; k++) {
+                int g = s->attrs[k].group;
+                /* the reference indexes textures[group] unchecked (raytracer.cpp:700-701) */
+                if (g < 0 || g >= m.n_tex) return fail(c, RT_E_INVALID, "mesh %d: triangle %d has texture group %d but the mesh has %d textures", mi, k, g, m.n_tex);
+            }
+    }
+    for (int64_t k = 0; k < s->n_nodes; k++) {
+        const rt_bvh_node &nd = s->nodes[k];
+        const int32_t idx[2] = {nd.L, nd.R}, cnt[2] = {nd.nL, nd.nR};
+        for (int q = 0; q < 2; q++) {
+            if (cnt[q] < 0) return fail(c, RT_E_INVALID, "node %lld: negative leaf count", (long long)k);
+            if (cnt[q] == 0 ? (idx[q] <= k || idx[q] >= s->n_nodes) : (idx[q] < 0 || (int64_t)idx[q] + cnt[q] > s->n_tris))
+                return fail(c, RT_E_INVALID, "node %lld: child %d out of range (inner children must have a larger index)", (long long)k, q);
+        }
+    }
+    for (int k = 0; k < s->n_tex; k++) {
+        const rt_texture &tx = s->tex[k];
+        if (tx.W <= 0 || tx.H <= 0 || tx.offset < 0 || tx.offset + (int64_t)tx.W * tx.H * 3 > s->texel_bytes)
+            return fail(c, RT_E_INVALID, "texture %d: outside the texel pool", k);
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_scene(c);
+    DScene d{};
+    int rc;
+    if ((rc = upload_array(c, s->spheres, (size_t)s->n_spheres, &d.spheres))) return rc;
+    if ((rc = upload_array(c, s->meshes, (size_t)s->n_meshes, &d.meshes))) return rc;
+    if ((rc = upload_array(c, s->nodes, (size_t)s->n_nodes, &d.nodes))) return rc;
+    if ((rc = upload_array(c, s->tris, (size_t)s->n_tris, &d.tris))) return rc;
+    if ((rc = upload_array(c, s->attrs, (size_t)s->n_tris, &d.attrs))) return rc;
+    if ((rc = upload_array(c, s->tex, (size_t)s->n_tex, &d.tex))) return rc;
+    if ((rc = upload_array(c, s->texels, (size_t)s->texel_bytes, &d.texels))) return rc;
+    double lut[256];
+    if (s->srgb_lut) memcpy(lut, s->srgb_lut, sizeof lut);
+    else for (int i = 0; i < 256; i++) lut[i] = pow(i / 255., 2.2); /* raytracer.cpp:713-715 */
+    if ((rc = upload_array(c, lut, 256, &d.lut))) return rc;
+    d.n_spheres = s->n_spheres;
+    d.n_meshes = s->n_meshes;
+    d.I = s->I;
+    for (int k = 0; k < 3; k++) d.L[k] = s->L[k];
+    c->light_ok = light != nullptr;
+    if (light) {
+        for (int k = 0; k < 3; k++) d.lightO[k] = light->O[k];
+        d.lightR = light->R;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream)); /* host arrays may be released after return */
+    c->sc = d;
+    c->lds_bytes = (s->n_spheres <= RT_LDS_SPHERES_MAX) ? (size_t)s->n_spheres * sizeof(rt_sphere) : 0;
+    c->have_scene = true;
+    return RT_OK;
+}
+
+static int check_render_args(rt_ctx *c, const rt_camera *cam, const rt_params *p, RenderArgs *ra) {
+    if (!c->have_scene) return fail(c, RT_E_STATE, "no scene uploaded");
+    if (!cam || !p) return fail(c, RT_E_INVALID, "camera or params is NULL");
+    if (p->W <= 0 || p->H <= 0 || (int64_t)p->W * p->H > 0x7fffffffLL) return fail(c, RT_E_INVALID, "bad image size %dx%d", p->W, p->H);
+    if (p->spp < 0 || p->spp_offset < 0) return fail(c, RT_E_INVALID, "negative spp or spp_offset");
+    if (p->max_rebond < 0 || p->max_rebond > 1000) return fail(c, RT_E_INVALID, "max_rebond %d out of range", p->max_rebond);
+    if (!(p->flags & RT_F_POINT_LIGHT) && !c->light_ok)
+        return fail(c, RT_E_INVALID, "objects[0] is not a sphere: the area-light estimator needs the light sphere there (raytracer.cpp:970, :1062)");
+    int j0 = p->rect[0], i0 = p->rect[1], j1 = p->rect[2], i1 = p->rect[3];
+    if (!j0 && !i0 && !j1 && !i1) { j1 = p->W; i1 = p->H; }
+    if (j0 < 0 || i0 < 0 || j1 > p->W || i1 > p->H || j0 >= j1 || i0 >= i1) return fail(c, RT_E_INVALID, "bad rect [%d,%d,%d,%d]", j0, i0, j1, i1);
+    ra->cam = *cam;
+    ra->p = *p;
+    ra->seed_mixed = 0;
+    {
+        uint64_t z = p->seed + 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        ra->seed_mixed = z ^ (z >> 31);
+    }
+    ra->j0 = j0; ra->i0 = i0; ra->j1 = j1; ra->i1 = i1;
+    return RT_OK;
+}
+
+/* samples per kernel launch: long renders are cut into several launches of bounded duration */
+static const int kSppPerLaunch = 64;
+
+int rt_render(rt_ctx *c, const rt_camera *cam, const rt_params *p, double *accum) {
+    if (!c) return RT_E_INVALID;
+    RenderArgs ra;
+    int rc = check_render_args(c, cam, p, &ra);
+    if (rc) return rc;
+    if (!accum) {
+        if (!c->accum || c->accW != p->W || c->accH != p->H) return fail(c, RT_E_STATE, "own accumulator not allocated for %dx%d: call rt_accum_clear first", p->W, p->H);
+        accum = c->accum;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rw = ra.j1 - ra.j0, rh = ra.i1 - ra.i0;
+    const int64_t tiles = (int64_t)((rw + 7) / 8) * ((rh + 7) / 8);
+    const int64_t threads = tiles * 64;
+    const unsigned grid = (unsigned)((threads + RT_BLOCK - 1) / RT_BLOCK);
+    c->last_launches = 0;
+    c->timed = false;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    for (int k = 0; k < p->spp; k += kSppPerLaunch) {
+        const int nk = (p->spp - k < kSppPerLaunch) ? (p->spp - k) : kSppPerLaunch;
+        if (p->flags & RT_F_COUNTERS)
+            hipLaunchKernelGGL(rt_render_kernel<true>, dim3(grid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, accum, c->d_counters);
+        else
+            hipLaunchKernelGGL(rt_render_kernel<false>, dim3(grid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, accum, c->d_counters);
+        HIPCHK(c, hipGetLastError());
+        c->last_launches++;
+    }
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    return RT_OK;
+}
+
+int rt_sync(rt_ctx *c) {
+    if (!c) return RT_E_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_last_render_ms(rt_ctx *c, double *ms, int32_t *n_launches) {
+    if (!c || !ms) return RT_E_INVALID;
+    if (!c->timed) return fail(c, RT_E_STATE, "no render recorded");
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float f = 0;
+    HIPCHK(c, hipEventElapsedTime(&f, c->ev0, c->ev1));
+    *ms = f;
+    if (n_launches) *n_launches = c->last_launches;
+    return RT_OK;
+}
+
+int rt_accum_clear(rt_ctx *c, int32_t W, int32_t H) {
+    if (!c) return RT_E_INVALID;
+    if (W <= 0 || H <= 0) return fail(c, RT_E_INVALID, "bad accumulator size");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->accum || c->accW != W || c->accH != H) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->accum) (void)hipFree(c->accum);
+        c->accum = nullptr;
+        if (hipMalloc((void **)&c->accum, (size_t)W * H * 3 * sizeof(double)) != hipSuccess) return fail(c, RT_E_NOMEM, "accumulator allocation failed");
+        c->accW = W;
+        c->accH = H;
+    }
+    HIPCHK(c, hipMemsetAsync(c->accum, 0, (size_t)W * H * 3 * sizeof(double), c->stream));
+    return RT_OK;
+}
+
+double *rt_accum_device_ptr(rt_ctx *c) { return c ? c->accum : nullptr; }
+
+int rt_accum_download(rt_ctx *c, double *host_out, int64_t n) {
+    if (!c || !host_out) return RT_E_INVALID;
+    if (!c->accum || n != (int64_t)c->accW * c->accH * 3) return fail(c, RT_E_INVALID, "rt_accum_download: size mismatch");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(host_out, c->accum, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_resolve(rt_ctx *c, const double *accum, int32_t W, int32_t H, double spp_total, uint8_t *rgb8_host) {
+    if (!c || !rgb8_host) return RT_E_INVALID;
+    if (W <= 0 || H <= 0) return fail(c, RT_E_INVALID, "bad size");
+    if (!accum) {
+        if (!c->accum || c->accW != W || c->accH != H) return fail(c, RT_E_STATE, "own accumulator not allocated for %dx%d", W, H);
+        accum = c->accum;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    uint8_t *d = nullptr;
+    const size_t nb = (size_t)W * H * 3;
+    if (hipMalloc((void **)&d, nb) != hipSuccess) return fail(c, RT_E_NOMEM, "resolve buffer allocation failed");
+    const int64_t n = (int64_t)W * H;
+    hipLaunchKernelGGL(rt_resolve_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, accum, W, H, spp_total, d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(rgb8_host, d, nb, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, RT_E_DEVICE, "rt_resolve: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_intersect_rays(rt_ctx *c, const double *rays, int64_t n, int32_t *obj_id, int32_t *tri_id, double *t, double *PN, double *albedo) {
+    if (!c) return RT_E_INVALID;
+    if (!c->have_scene) return fail(c, RT_E_STATE, "no scene uploaded");
+    if (n < 0 || (n && !rays)) return fail(c, RT_E_INVALID, "bad ray array");
+    if (n == 0) return RT_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    /* one device block: rays | obj | tri | t | PN | albedo */
+    const size_t b_rays = (size_t)n * 6 * 8, b_i = (size_t)n * 4, b_t = (size_t)n * 8, b_pn = (size_t)n * 6 * 8, b_al = (size_t)n * 3 * 8;
+    unsigned char *d = nullptr;
+    if (hipMalloc((void **)&d, b_rays + b_t + b_pn + b_al + 2 * b_i) != hipSuccess) return fail(c, RT_E_NOMEM, "probe buffer allocation failed");
+    double *d_rays = (double *)d, *d_t = (double *)(d + b_rays), *d_pn = (double *)(d + b_rays + b_t), *d_al = (double *)(d + b_rays + b_t + b_pn);
+    int32_t *d_obj = (int32_t *)(d + b_rays + b_t + b_pn + b_al), *d_tri = d_obj + n;
+    hipError_t e = hipMemcpyAsync(d_rays, rays, b_rays, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rt_intersect_kernel, dim3((unsigned)((n + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, d_rays, n, d_obj, d_tri, d_t, d_pn, d_al);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && obj_id) e = hipMemcpyAsync(obj_id, d_obj, b_i, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && tri_id) e = hipMemcpyAsync(tri_id, d_tri, b_i, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && t) e = hipMemcpyAsync(t, d_t, b_t, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && PN) e = hipMemcpyAsync(PN, d_pn, b_pn, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && albedo) e = hipMemcpyAsync(albedo, d_al, b_al, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, RT_E_DEVICE, "rt_intersect_rays: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_sample_radiance(rt_ctx *c, const rt_camera *cam, const rt_params *p, const int32_t *ijk, int64_t n, double *out) {
+    if (!c) return RT_E_INVALID;
+    RenderArgs ra;
+    int rc = check_render_args(c, cam, p, &ra);
+    if (rc) return rc;
+    if (n < 0 || (n && (!ijk || !out))) return fail(c, RT_E_INVALID, "bad sample list");
+    if (n == 0) return RT_OK;
+    for (int64_t q = 0; q < n; q++)
+        if (ijk[3 * q] < 0 || ijk[3 * q] >= p->H || ijk[3 * q + 1] < 0 || ijk[3 * q + 1] >= p->W || ijk[3 * q + 2] < 0)
+            return fail(c, RT_E_INVALID, "sample %lld outside the image", (long long)q);
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned char *d = nullptr;
+    const size_t b_in = (size_t)n * 3 * 4, b_out = (size_t)n * 3 * 8;
+    if (hipMalloc((void **)&d, b_out + b_in) != hipSuccess) return fail(c, RT_E_NOMEM, "probe buffer allocation failed");
+    double *d_out = (double *)d;
+    int32_t *d_in = (int32_t *)(d + b_out);
+    hipError_t e = hipMemcpyAsync(d_in, ijk, b_in, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rt_sample_kernel, dim3((unsigned)((n + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, d_in, n, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, b_out, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, RT_E_DEVICE, "rt_sample_radiance: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_get_counters(rt_ctx *c, rt_counters *out) {
+    if (!c || !out) return RT_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, c->d_counters, sizeof(rt_counters), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_reset_counters(rt_ctx *c) {
+    if (!c) return RT_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(rt_counters), c->stream));
+    return RT_OK;
+}
+
+} /* extern "C" */

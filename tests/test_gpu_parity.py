@@ -1,0 +1,157 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs. Bars: hit identity (object id, triangle id) and hit parameter t bit-exact;
+noise-free radiance within 1e-4 relative per pixel (in practice ~1e-15); per-sample stochastic
+radiance within 1e-9 relative for all but a handful of samples (libm differences in sin/cos/log can
+move a ray across a silhouette or flip a Fresnel coin)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene_pair(ob, scenes, builder, **kw):
+    out = builder(**kw)
+    s, cam, flags = out[0], out[1], out[2]
+    objs = scenes.export_objects(s)
+    return s, cam, flags, ob.OracleScene(objs, s.I, s.L)
+
+
+def _check_hits(g, o):
+    assert np.array_equal(g["obj"], o["obj"])
+    assert np.array_equal(g["tri"], o["tri"])
+    assert np.array_equal(g["t"], o["t"])  # bit-exact
+    hit = o["obj"] >= 0
+    assert np.array_equal(g["P"][hit], o["P"][hit])
+    assert np.array_equal(g["N"][hit], o["N"][hit], equal_nan=True)
+    assert np.array_equal(g["albedo"][hit], o["albedo"][hit])
+
+
+def _rel_err(a, b):
+    """per-sample relative error, NaN == NaN counts as equal (axis-aligned normals, random_cos)"""
+    both_nan = np.isnan(a) & np.isnan(b)
+    d = np.abs(a - b) / np.maximum(np.abs(b), 1e-3)
+    d[both_nan] = 0
+    d[np.isnan(d)] = np.inf
+    return d.max(axis=-1)
+
+
+@pytest.mark.parametrize("W", [64, 257])
+def test_primary_hits_sphere_room(gpu, rta, scenes, ob, W):
+    s, cam, flags, orc = _scene_pair(ob, scenes, scenes.sphere_room, W=W)
+    gpu.upload(s)
+    rays, _ = ob.primary_rays(cam, W, W)
+    _check_hits(gpu.intersect_rays(rays), orc.intersect_rays(rays))
+
+
+def test_primary_hits_mesh_room(gpu, rta, scenes, ob):
+    W = 160
+    s, cam, flags, orc = _scene_pair(ob, scenes, scenes.mesh_room, W=W, n_tris=30000, tex_size=128)
+    gpu.upload(s)
+    rays, _ = ob.primary_rays(cam, W, W)
+    g, o = gpu.intersect_rays(rays), orc.intersect_rays(rays)
+    assert (o["tri"] >= 0).sum() > 500
+    _check_hits(g, o)
+
+
+def test_random_rays_battle(gpu, rta, scenes, ob):
+    """incoherent rays from inside the room against the 12-mesh scene (reduced triangle count)"""
+    s, cam, flags, meta = scenes.battle(W=64, tri_scale=0.1, tex_size=64)
+    orc = ob.OracleScene(scenes.export_objects(s), s.I, s.L)
+    gpu.upload(s)
+    rng = np.random.default_rng(5)
+    n = 20000
+    org = np.stack([rng.uniform(-30, 30, n), rng.uniform(-5, 40, n), rng.uniform(-40, 50, n)], 1)
+    d = rng.normal(size=(n, 3))
+    d /= np.sqrt((d * d).sum(1))[:, None]
+    rays = np.concatenate([org, d], 1)
+    g, o = gpu.intersect_rays(rays), orc.intersect_rays(rays)
+    assert (o["tri"] >= 0).sum() > 300
+    _check_hits(g, o)
+
+
+def test_degenerate_rays(gpu, rta, scenes, ob):
+    """axis-parallel directions (division by zero in the slab test), zero direction, NaN"""
+    s, cam, flags, orc = _scene_pair(ob, scenes, scenes.mesh_room, W=64, n_tris=3000, tex_size=32)
+    gpu.upload(s)
+    rays = np.array([[0, 30, 55, 0, 0, -1], [0, 30, 55, 0, -1, 0], [0, 30, 55, 1, 0, 0], [0, -2, 0, 0, 0, -1], [0, 5, 0, 0, -1, 0],
+                     [0, 30, 55, 0, 0, 0], [0, 30, 55, np.nan, 0, -1], [0, 0, 0, 0, 1, 0], [0, 30, 55, 0, -0.5, -1]], np.float64)
+    _check_hits(gpu.intersect_rays(rays), orc.intersect_rays(rays))
+    assert gpu.intersect_rays(np.empty((0, 6)))["obj"].shape == (0,)
+
+
+def test_deterministic_room_radiance(gpu, rta, scenes, ob):
+    """cfg1 at reduced size: noise-off path (point light, hard shadows, mirror, refraction), 1 spp"""
+    W = 128
+    s, cam, flags, orc = _scene_pair(ob, scenes, scenes.sphere_room_deterministic, W=W)
+    gpu.upload(s)
+    p = rta.make_params(W, W, 1, flags=flags)
+    gpu.accum_clear(W, W)
+    gpu.render(cam, p)
+    g = gpu.accum_download(W, W)
+    o = orc.render(cam, p)
+    assert o.max() > 1e3 and (o > 0).mean() > 0.5
+    rel = np.abs(g - o) / np.maximum(np.abs(o), 1e-6)
+    assert rel.max() < 1e-4, rel.max()  # the bar; measured ~1e-15
+    assert rel.max() < 1e-12
+    assert np.array_equal(gpu.resolve(W, W, 1), ob.resolve(o, 1))
+
+
+@pytest.mark.parametrize("name,kw", [("sphere_room", dict(W=96)), ("mesh_room", dict(W=96, n_tris=20000, tex_size=128))])
+def test_stochastic_per_sample(gpu, rta, scenes, ob, name, kw):
+    s, cam, flags, orc = _scene_pair(ob, scenes, getattr(scenes, name), **kw)
+    gpu.upload(s)
+    W = kw["W"]
+    p = rta.make_params(W, W, 4, flags=flags)
+    ijk = np.array([(i, j, k) for i in range(0, W, 2) for j in range(0, W, 2) for k in range(4)], np.int32)
+    g = gpu.sample_radiance(cam, p, ijk)
+    o = orc.sample_radiance(cam, p, ijk)
+    rel = _rel_err(g, o)
+    bad = (rel > 1e-9).sum()
+    assert bad <= max(2, len(ijk) // 2000), (bad, len(ijk), np.sort(rel)[-5:])
+
+
+def test_render_equals_sum_of_samples(gpu, rta, scenes, ob):
+    """rt_render adds samples k = spp_offset.. in order; rect and spp_offset sharding agree with the oracle"""
+    W = 64
+    s, cam, flags, orc = _scene_pair(ob, scenes, scenes.sphere_room, W=W)
+    gpu.upload(s)
+    gpu.accum_clear(W, W)
+    gpu.render(cam, rta.make_params(W, W, 3, spp_offset=0, rect=(8, 16, 56, 48)))
+    gpu.render(cam, rta.make_params(W, W, 2, spp_offset=3, rect=(8, 16, 56, 48)))
+    g = gpu.accum_download(W, W)
+    o = orc.render(cam, rta.make_params(W, W, 5, rect=(8, 16, 56, 48)))
+    assert np.all(g[:16] == 0) and np.all(g[:, :8] == 0) and np.all(g[48:] == 0) and np.all(g[:, 56:] == 0)
+    rel = np.abs(g - o) / np.maximum(np.abs(o), 1e-3)
+    assert (rel > 1e-9).sum() <= 6, np.sort(rel.ravel())[-8:]
+
+
+def test_counters_match_oracle(gpu, rta, scenes, ob):
+    """rays / box tests / nodes / triangle tests counted under the reference's traversal semantics"""
+    W = 64
+    s, cam, flags, orc = _scene_pair(ob, scenes, scenes.mesh_room, W=W, n_tris=5000, tex_size=32)
+    gpu.upload(s)
+    p = rta.make_params(W, W, 2, flags=rta.RT_F_COUNTERS)
+    gpu.reset_counters()
+    gpu.accum_clear(W, W)
+    gpu.render(cam, p)
+    gc = gpu.counters()
+    oc = rta.rt_counters()
+    orc.render(cam, p, counters=oc)
+    oc = oc.as_dict()
+    assert gc["paths"] == oc["paths"] == W * W * 2
+    for k in ("rays", "box_tests", "nodes", "tris", "mesh_calls"):
+        assert abs(gc[k] - oc[k]) <= 1e-4 * oc[k] + 50, (k, gc[k], oc[k])
+
+
+def test_errors(gpu, rta, scenes):
+    s = rta.Scene()
+    m = rta.TriangleMesh((1, 1, 1))
+    s.add(m)  # objects[0] is not a sphere and the mesh has no BVH
+    with pytest.raises(rta.RTError):
+        gpu.upload(s)
+    s2, cam, flags = scenes.sphere_room_deterministic(32)
+    gpu.upload(s2)
+    with pytest.raises(rta.RTError):  # area-light estimator without a light sphere at objects[0]... objects[0] IS a sphere here
+        gpu.render(cam, rta.make_params(32, 32, 1, rect=(0, 0, 64, 64)))
+    with pytest.raises(rta.RTError):
+        gpu.render(cam, rta.make_params(32, 32, 1))  # accumulator not allocated for 32x32
