@@ -176,6 +176,8 @@ typedef struct rt_counters {
     uint64_t nodes;      /* BVH records popped (inner Noeuds visited) */
     uint64_t tris;       /* triangle tests (raytracer.cpp:670-687) */
     uint64_t mesh_calls; /* TriangleMesh::intersect calls that passed the root box */
+    uint64_t diffuse;    /* diffuse vertices shaded (raytracer.cpp:1059-1088) */
+    uint64_t specular;   /* mirror / dielectric vertices (raytracer.cpp:974-1021) */
 } rt_counters;
 
 typedef struct rt_ctx rt_ctx;

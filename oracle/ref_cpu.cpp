@@ -108,7 +108,7 @@ struct Obj {
     Mesh *mesh;
 };
 struct Cnt {
-    uint64_t paths, rays, box_tests, nodes, tris, mesh_calls;
+    uint64_t paths, rays, box_tests, nodes, tris, mesh_calls, diffuse, specular;
 };
 
 } // namespace
@@ -366,11 +366,13 @@ V3 get_color(const Ctx &cx, Rng &g, const Ray &r, int rebond, bool lastDiffuse) 
         return mk(0., 0., 0.);
     }
     if (h.mirror) { /* :974-979 */
+        if (cx.cnt) cx.cnt->specular++;
         V3 reflectedDir = sub(r.u, smul(2 * dot(r.u, N), N));
         Ray rr{add(P, smul(epsilon, N)), reflectedDir};
         return get_color(cx, g, rr, rebond + 1, false);
     }
     if (h.transp) { /* :982-1021 */
+        if (cx.cnt) cx.cnt->specular++;
         double n1 = 1, n2 = cx.p->ior;
         V3 N2 = N;
         if (dot(r.u, N) > 0) {
@@ -402,6 +404,7 @@ V3 get_color(const Ctx &cx, Rng &g, const Ray &r, int rebond, bool lastDiffuse) 
         return get_color(cx, g, rr, rebond + 1, false);
     }
     /* diffuse */
+    if (cx.cnt) cx.cnt->diffuse++;
     if (fl & RT_F_POINT_LIGHT) { /* :1040-1055 */
         V3 PL = sub(sc.L, P);
         double d = sqrt(norm2(PL));
@@ -485,6 +488,7 @@ void rect_of(const rt_params &p, int &j0, int &i0, int &j1, int &i1) {
 void cnt_add(rt_counters *dst, const Cnt &c) {
     dst->paths += c.paths; dst->rays += c.rays; dst->box_tests += c.box_tests;
     dst->nodes += c.nodes; dst->tris += c.tris; dst->mesh_calls += c.mesh_calls;
+    dst->diffuse += c.diffuse; dst->specular += c.specular;
 }
 
 } // namespace
@@ -678,6 +682,7 @@ void orc_render(const orc_scene *s, const rt_camera *cam, const rt_params *p, do
         {
             total.paths += c.paths; total.rays += c.rays; total.box_tests += c.box_tests;
             total.nodes += c.nodes; total.tris += c.tris; total.mesh_calls += c.mesh_calls;
+            total.diffuse += c.diffuse; total.specular += c.specular;
         }
     }
     if (counters) cnt_add(counters, total);

@@ -38,7 +38,7 @@ class rt_params(C.Structure):
 
 class rt_counters(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("box_tests", C.c_uint64), ("nodes", C.c_uint64),
-                ("tris", C.c_uint64), ("mesh_calls", C.c_uint64)]
+                ("tris", C.c_uint64), ("mesh_calls", C.c_uint64), ("diffuse", C.c_uint64), ("specular", C.c_uint64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_render_kernel(DScene sc, RenderAr
     const rt_sphere *sph = stage_spheres(sc, reinterpret_cast<rt_sphere *>(lds_raw));
     int i, j;
     const bool live = lane_pixel(ra, i, j);
-    Cnt cnt = {0, 0, 0, 0, 0, 0};
+    Cnt cnt = {0, 0, 0, 0, 0, 0, 0, 0};
     if (live) {
         V3 a = trace_pixel<CNT>(sc, sph, ra, i, j, k0, nk, cnt);
         double *px = accum + ((int64_t)i * ra.p.W + j) * 3;
@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_sample_kernel(DScene sc, RenderAr
     const rt_sphere *sph = stage_spheres(sc, reinterpret_cast<rt_sphere *>(lds_raw));
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
-    Cnt cnt = {0, 0, 0, 0, 0, 0};
+    Cnt cnt = {0, 0, 0, 0, 0, 0, 0, 0};
     V3 a = trace_pixel<false>(sc, sph, ra, ijk[3 * q], ijk[3 * q + 1], ijk[3 * q + 2], 1, cnt);
     out[3 * q] = a.x;
     out[3 * q + 1] = a.y;
@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_intersect_kernel(DScene sc, const
     if (q >= n) return;
     V3 C = ld3(rays + 6 * q), u = ld3(rays + 6 * q + 3);
     HitRec h;
-    Cnt cnt = {0, 0, 0, 0, 0, 0};
+    Cnt cnt = {0, 0, 0, 0, 0, 0, 0, 0};
     bool ok = scene_closest<false>(sc, sph, C, u, h, cnt);
     obj_id[q] = ok ? h.obj : -1;
     tri_id[q] = (ok && h.mesh >= 0) ? sc.tris[h.prim].orig_id : -1;

@@ -90,7 +90,7 @@ __device__ __forceinline__ double rng_uniform(uint64_t key, uint32_t n) {
 }
 
 struct Cnt {
-    uint64_t paths, rays, box_tests, nodes, tris, mesh_calls;
+    uint64_t paths, rays, box_tests, nodes, tris, mesh_calls, diffuse, specular;
 };
 
 /* BoudingBox::intersect, raytracer.cpp:163-186 (six true divisions, no bound on t) */
@@ -374,12 +374,14 @@ __device__ __forceinline__ V3 trace_pixel(const DScene &sc, const rt_sphere *sph
             hit_surface(sc, sph, rC, ru, h, s);
             const V3 P = s.P, N = s.N;
             if (s.flags & RT_MAT_MIRROR) { /* :974-979 */
+                if (CNT) cnt.specular++;
                 V3 rd = sub(ru, smul(2 * dot(ru, N), N));
                 rC = add(P, smul(epsilon, N));
                 ru = rd;
                 rebond++;
                 lastDiffuse = false;
             } else if (s.flags & RT_MAT_TRANSPARENT) { /* :982-1021 */
+                if (CNT) cnt.specular++;
                 double n1 = 1, n2 = p.ior;
                 V3 N2 = N;
                 if (dot(ru, N) > 0) {
@@ -412,6 +414,7 @@ __device__ __forceinline__ V3 trace_pixel(const DScene &sc, const rt_sphere *sph
                 rebond++;
                 lastDiffuse = false;
             } else { /* diffuse: direct light now, indirect ray after the shadow query */
+                if (CNT) cnt.diffuse++;
                 V3 shC = add(P, smul(0.00001, N)), shU;
                 if (fl & RT_F_POINT_LIGHT) { /* :1040-1055 */
                     V3 PL = sub(Lpos, P);
@@ -458,10 +461,10 @@ __device__ __forceinline__ V3 trace_pixel(const DScene &sc, const rt_sphere *sph
 
 /* wave-reduce a counter set and add it to global memory with one atomic per field per wave */
 __device__ __forceinline__ void flush_counters(const Cnt &c, rt_counters *out) {
-    uint64_t v[6] = {c.paths, c.rays, c.box_tests, c.nodes, c.tris, c.mesh_calls};
+    uint64_t v[8] = {c.paths, c.rays, c.box_tests, c.nodes, c.tris, c.mesh_calls, c.diffuse, c.specular};
     unsigned long long *o = reinterpret_cast<unsigned long long *>(out);
 #pragma unroll
-    for (int q = 0; q < 6; q++) {
+    for (int q = 0; q < 8; q++) {
         uint64_t x = v[q];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_xor((unsigned long long)x, off, 64);
         if ((threadIdx.x & 63) == 0 && x) atomicAdd(o + q, (unsigned long long)x);

@@ -139,7 +139,7 @@ def test_counters_match_oracle(gpu, rta, scenes, ob):
     orc.render(cam, p, counters=oc)
     oc = oc.as_dict()
     assert gc["paths"] == oc["paths"] == W * W * 2
-    for k in ("rays", "box_tests", "nodes", "tris", "mesh_calls"):
+    for k in ("rays", "box_tests", "nodes", "tris", "mesh_calls", "diffuse", "specular"):
         assert abs(gc[k] - oc[k]) <= 1e-4 * oc[k] + 50, (k, gc[k], oc[k])
 
 
