@@ -67,13 +67,20 @@ typedef struct rt_bvh_node {
  * (raytracer.cpp:269-278).  A, e1 = B-A, e2 = C-A are what the test at
  * raytracer.cpp:673-677 derives from the three vertices; they do not depend on
  * the ray, so they are formed once on the host with the same two subtractions.
- * orig_id = index of the triangle in OBJ face-fan order (before buildBVH). */
+ * orig_id = index of the triangle in OBJ face-fan order (before buildBVH);
+ * mesh = index into rt_scene_desc.meshes.
+ * ORDER: within a mesh, triangles are stored in the order in which the
+ * reference's traversal visits them (it pops fd before fg,
+ * raytracer.cpp:656-665: leaves in descending `debut`, ascending i inside a
+ * leaf, :670), and meshes are stored in ascending object_id. "First visited
+ * wins an exact tie in t" (strict '<' at :690 and :938) is then "the lower
+ * array position wins", independent of the order a GPU traverses in. */
 typedef struct rt_tri {
     double A[3];
     double e1[3];
     double e2[3];
     int32_t orig_id;
-    int32_t pad;
+    int32_t mesh;
 } rt_tri; /* 80 bytes */
 
 /* Shading attributes of a triangle, same index as rt_tri: the three vertex

@@ -16,32 +16,40 @@
 
 using namespace rtd;
 
-#define RT_BLOCK 256
+#define RT_BLOCK 64 /* one workgroup = one wave: the LDS pool of rt_device.hip.h is per wave */
 
 /* ---------------------------------------------------------------------------------------------
  * kernels
  * ------------------------------------------------------------------------------------------- */
 
-/* Stage the sphere list in LDS (every ray tests every sphere: raytracer.cpp:934-938). */
-__device__ __forceinline__ const rt_sphere *stage_spheres(const DScene &sc, rt_sphere *lds) {
-    if (sc.n_spheres > RT_LDS_SPHERES_MAX) return sc.spheres;
+/* LDS of the wave; sphere lists of up to RT_LDS_SPHERES_MAX entries are staged behind the node stack
+ * (every ray tests every sphere: raytracer.cpp:934-938), longer lists are read from global memory
+ * with wave-uniform addresses. */
+__device__ __forceinline__ WaveLDS *wave_setup(const DScene &sc, unsigned char *lds_raw, const rt_sphere **sph) {
+    WaveLDS *w = reinterpret_cast<WaveLDS *>(lds_raw);
+    if (sc.n_spheres > RT_LDS_SPHERES_MAX) {
+        *sph = sc.spheres;
+        return w;
+    }
+    rt_sphere *dst = const_cast<rt_sphere *>(lds_spheres(w, sc.node_cap));
     const int n16 = sc.n_spheres * (int)(sizeof(rt_sphere) / 16);
     const uint4 *src = reinterpret_cast<const uint4 *>(sc.spheres);
-    uint4 *dst = reinterpret_cast<uint4 *>(lds);
-    for (int q = threadIdx.x; q < n16; q += blockDim.x) dst[q] = src[q];
-    __syncthreads();
-    return lds;
+    uint4 *d16 = reinterpret_cast<uint4 *>(dst);
+    for (int q = threadIdx.x; q < n16; q += RT_BLOCK) d16[q] = src[q];
+    wave_sync();
+    *sph = dst;
+    return w;
 }
 
 /* pixel of a lane: 8x8 pixel tiles per wave so the camera rays of a wave stay together */
 __device__ __forceinline__ bool lane_pixel(const RenderArgs &ra, int &i, int &j) {
     const int rw = ra.j1 - ra.j0, rh = ra.i1 - ra.i0;
     const int tiles_x = (rw + 7) >> 3;
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int tile = gid >> 6, lane = gid & 63;
+    const int tile = blockIdx.x, lane = threadIdx.x & 63;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     j = ra.j0 + tx * 8 + (lane & 7);
     i = ra.i0 + ty * 8 + (lane >> 3);
+    (void)rh;
     return (j < ra.j1) && (i < ra.i1);
 }
 
@@ -49,12 +57,13 @@ template <bool CNT>
 __global__ void __launch_bounds__(RT_BLOCK) rt_render_kernel(DScene sc, RenderArgs ra, int k0, int nk, double *accum,
                                                              rt_counters *counters) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    const rt_sphere *sph = stage_spheres(sc, reinterpret_cast<rt_sphere *>(lds_raw));
+    const rt_sphere *sph;
+    WaveLDS *w = wave_setup(sc, lds_raw, &sph);
     int i, j;
     const bool live = lane_pixel(ra, i, j);
     Cnt cnt = {0, 0, 0, 0, 0, 0, 0, 0};
+    V3 a = trace_pixel<CNT>(sc, w, sph, ra, live, i, j, k0, nk, cnt);
     if (live) {
-        V3 a = trace_pixel<CNT>(sc, sph, ra, i, j, k0, nk, cnt);
         double *px = accum + ((int64_t)i * ra.p.W + j) * 3;
         /* one lane owns the pixel for the whole launch and launches on a stream are ordered */
         px[0] = px[0] + a.x;
@@ -67,27 +76,34 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_render_kernel(DScene sc, RenderAr
 /* one path per thread: radiance of sample (i, j, k) */
 __global__ void __launch_bounds__(RT_BLOCK) rt_sample_kernel(DScene sc, RenderArgs ra, const int32_t *ijk, int64_t n, double *out) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    const rt_sphere *sph = stage_spheres(sc, reinterpret_cast<rt_sphere *>(lds_raw));
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n) return;
+    const rt_sphere *sph;
+    WaveLDS *w = wave_setup(sc, lds_raw, &sph);
+    const int64_t q = (int64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    const bool live = q < n;
     Cnt cnt = {0, 0, 0, 0, 0, 0, 0, 0};
-    V3 a = trace_pixel<false>(sc, sph, ra, ijk[3 * q], ijk[3 * q + 1], ijk[3 * q + 2], 1, cnt);
-    out[3 * q] = a.x;
-    out[3 * q + 1] = a.y;
-    out[3 * q + 2] = a.z;
+    const int i = live ? ijk[3 * q] : 0, j = live ? ijk[3 * q + 1] : 0, k = live ? ijk[3 * q + 2] : 0;
+    V3 a = trace_pixel<false>(sc, w, sph, ra, live, i, j, k, 1, cnt);
+    if (live) {
+        out[3 * q] = a.x;
+        out[3 * q + 1] = a.y;
+        out[3 * q + 2] = a.z;
+    }
 }
 
 /* Scene::intersect probe */
 __global__ void __launch_bounds__(RT_BLOCK) rt_intersect_kernel(DScene sc, const double *rays, int64_t n, int32_t *obj_id, int32_t *tri_id,
                                                                 double *t, double *PN, double *albedo) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    const rt_sphere *sph = stage_spheres(sc, reinterpret_cast<rt_sphere *>(lds_raw));
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n) return;
-    V3 C = ld3(rays + 6 * q), u = ld3(rays + 6 * q + 3);
+    const rt_sphere *sph;
+    WaveLDS *w = wave_setup(sc, lds_raw, &sph);
+    const int64_t q = (int64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    const bool live = q < n;
+    V3 C = mk(0, 0, 0), u = mk(0, 0, 1);
+    if (live) { C = ld3(rays + 6 * q); u = ld3(rays + 6 * q + 3); }
     HitRec h;
     Cnt cnt = {0, 0, 0, 0, 0, 0, 0, 0};
-    bool ok = scene_closest<false>(sc, sph, C, u, h, cnt);
+    bool ok = scene_closest_wave<false>(sc, w, sph, live, C, u, h, cnt);
+    if (!live) return;
     obj_id[q] = ok ? h.obj : -1;
     tri_id[q] = (ok && h.mesh >= 0) ? sc.tris[h.prim].orig_id : -1;
     t[q] = h.t;
@@ -136,6 +152,7 @@ struct rt_ctx {
     double *accum = nullptr;
     int accW = 0, accH = 0;
     rt_counters *d_counters = nullptr;
+    int *d_overflow = nullptr;
 };
 
 static std::string g_create_err;
@@ -175,6 +192,18 @@ static int upload_array(rt_ctx *c, const T *host, size_t n, const T **dev_out) {
     return RT_OK;
 }
 
+/* the pool's node stack is sized from the validated BVH depth; a push past it is dropped and flagged */
+static int check_overflow(rt_ctx *c) {
+    int flag = 0;
+    HIPCHK(c, hipMemcpyAsync(&flag, c->d_overflow, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (flag) {
+        (void)hipMemsetAsync(c->d_overflow, 0, sizeof(int), c->stream);
+        return fail(c, RT_E_DEVICE, "traversal pool overflow: results of the last launch are incomplete");
+    }
+    return RT_OK;
+}
+
 extern "C" {
 
 const char *rt_version(void) { return "rt_amd 0.1 (gfx950, fp64, -ffp-contract=off)"; }
@@ -191,7 +220,8 @@ int rt_create(int device, rt_ctx **out) {
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
         (e = hipMalloc((void **)&c->d_counters, sizeof(rt_counters))) != hipSuccess ||
-        (e = hipMemset(c->d_counters, 0, sizeof(rt_counters))) != hipSuccess) {
+        (e = hipMemset(c->d_counters, 0, sizeof(rt_counters))) != hipSuccess ||
+        (e = hipMalloc((void **)&c->d_overflow, sizeof(int))) != hipSuccess || (e = hipMemset(c->d_overflow, 0, sizeof(int))) != hipSuccess) {
         fail(nullptr, RT_E_DEVICE, "rt_create: %s", hipGetErrorString(e));
         delete c;
         return RT_E_DEVICE;
@@ -207,6 +237,7 @@ void rt_destroy(rt_ctx *c) {
     free_scene(c);
     if (c->accum) (void)hipFree(c->accum);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->d_overflow) (void)hipFree(c->d_overflow);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -225,7 +256,9 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
     if ((s->n_spheres && !s->spheres) || (s->n_meshes && !s->meshes) || (s->n_nodes && !s->nodes) ||
         (s->n_tris && (!s->tris || !s->attrs)) || (s->n_tex && (!s->tex || !s->texels)))
         return fail(c, RT_E_INVALID, "rt_upload_scene: NULL array with non-zero count");
-    if (s->n_tris > 0x7fffffffLL || s->n_nodes > 0x7fffffffLL) return fail(c, RT_E_INVALID, "rt_upload_scene: more than 2^31 triangles or nodes");
+    if (s->n_tris >= (1LL << 26) || s->n_nodes >= (1LL << RT_NODE_BITS)) return fail(c, RT_E_INVALID, "rt_upload_scene: at most 2^26 triangles and BVH records");
+    if (s->n_meshes > 0 && s->n_tris != (int64_t)s->meshes[s->n_meshes - 1].first_tri + s->meshes[s->n_meshes - 1].n_tris)
+        return fail(c, RT_E_INVALID, "rt_upload_scene: n_tris does not match the mesh ranges");
     /* validate everything the kernels index with, so a bad description is an error and not a GPU fault */
     const int n_obj = s->n_spheres + s->n_meshes;
     std::vector<char> seen(n_obj, 0);
@@ -236,13 +269,21 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
         seen[id] = 1;
         if (id == 0) light = &s->spheres[i];
     }
+    int max_depth = 0;
     for (int mi = 0; mi < s->n_meshes; mi++) {
         const rt_mesh &m = s->meshes[mi];
+        if (m.max_depth > max_depth) max_depth = m.max_depth;
+        /* ties between meshes go to the lower objectId (raytracer.cpp:938) = the lower triangle position */
+        if (mi > 0 && (m.object_id <= s->meshes[mi - 1].object_id || m.first_tri != s->meshes[mi - 1].first_tri + s->meshes[mi - 1].n_tris))
+            return fail(c, RT_E_INVALID, "mesh %d: meshes must be in ascending object_id with consecutive triangle ranges", mi);
+        if (mi == 0 && m.first_tri != 0) return fail(c, RT_E_INVALID, "mesh 0: first_tri must be 0");
         if (m.object_id < 0 || m.object_id >= n_obj || seen[m.object_id]) return fail(c, RT_E_INVALID, "mesh %d: object_id %d invalid or repeated", mi, m.object_id);
         seen[m.object_id] = 1;
         if (m.n_tris < 0 || m.first_tri < 0 || (int64_t)m.first_tri + m.n_tris > s->n_tris) return fail(c, RT_E_INVALID, "mesh %d: triangle range outside the triangle array", mi);
         if (m.n_tex < 0 || m.first_tex < 0 || m.first_tex + m.n_tex > s->n_tex) return fail(c, RT_E_INVALID, "mesh %d: texture range outside the texture array", mi);
-        if (m.max_depth + 2 > RT_STACK_MAX) return fail(c, RT_E_INVALID, "mesh %d: BVH depth %d exceeds the traversal stack (%d)", mi, m.max_depth, RT_STACK_MAX - 2);
+        if (m.max_depth < 0 || m.max_depth > RT_MAX_DEPTH) return fail(c, RT_E_INVALID, "mesh %d: BVH depth %d outside [0,%d]", mi, m.max_depth, RT_MAX_DEPTH);
+        for (int32_t k = m.first_tri; k < m.first_tri + m.n_tris; k++)
+            if (s->tris[k].mesh != mi) return fail(c, RT_E_INVALID, "mesh %d: triangle %d carries mesh index %d", mi, k, s->tris[k].mesh);
         if (m.root_count < 0) return fail(c, RT_E_INVALID, "mesh %d: negative root_count", mi);
         if (m.root_count > 0) {
             if (m.root < m.first_tri || (int64_t)m.root + m.root_count > (int64_t)m.first_tri + m.n_tris) return fail(c, RT_E_INVALID, "mesh %d: root leaf outside its triangles", mi);
@@ -298,8 +339,11 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
         d.lightR = light->R;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream)); /* host arrays may be released after return */
+    d.node_cap = RT_WAVE * (RT_MESH_CHUNK + max_depth + 2);
+    d.overflow = c->d_overflow;
     c->sc = d;
-    c->lds_bytes = (s->n_spheres <= RT_LDS_SPHERES_MAX) ? (size_t)s->n_spheres * sizeof(rt_sphere) : 0;
+    c->lds_bytes = sizeof(WaveLDS) + (size_t)d.node_cap * 4 + 16 + ((s->n_spheres <= RT_LDS_SPHERES_MAX) ? (size_t)s->n_spheres * sizeof(rt_sphere) : 0);
+    if (c->lds_bytes > 64 * 1024) return fail(c, RT_E_INVALID, "rt_upload_scene: per-wave LDS of %zu bytes exceeds 64 KiB", c->lds_bytes);
     c->have_scene = true;
     return RT_OK;
 }
@@ -343,8 +387,8 @@ int rt_render(rt_ctx *c, const rt_camera *cam, const rt_params *p, double *accum
     HIPCHK(c, hipSetDevice(c->device));
     const int rw = ra.j1 - ra.j0, rh = ra.i1 - ra.i0;
     const int64_t tiles = (int64_t)((rw + 7) / 8) * ((rh + 7) / 8);
-    const int64_t threads = tiles * 64;
-    const unsigned grid = (unsigned)((threads + RT_BLOCK - 1) / RT_BLOCK);
+    if (tiles > 0x7fffffffLL) return fail(c, RT_E_INVALID, "too many tiles");
+    const unsigned grid = (unsigned)tiles;
     c->last_launches = 0;
     c->timed = false;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -365,7 +409,7 @@ int rt_render(rt_ctx *c, const rt_camera *cam, const rt_params *p, double *accum
 int rt_sync(rt_ctx *c) {
     if (!c) return RT_E_INVALID;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return RT_OK;
+    return check_overflow(c);
 }
 
 int rt_last_render_ms(rt_ctx *c, double *ms, int32_t *n_launches) {
@@ -403,7 +447,7 @@ int rt_accum_download(rt_ctx *c, double *host_out, int64_t n) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(host_out, c->accum, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return RT_OK;
+    return check_overflow(c);
 }
 
 int rt_resolve(rt_ctx *c, const double *accum, int32_t W, int32_t H, double spp_total, uint8_t *rgb8_host) {
@@ -424,7 +468,7 @@ int rt_resolve(rt_ctx *c, const double *accum, int32_t W, int32_t H, double spp_
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(c, RT_E_DEVICE, "rt_resolve: %s", hipGetErrorString(e));
-    return RT_OK;
+    return check_overflow(c);
 }
 
 int rt_intersect_rays(rt_ctx *c, const double *rays, int64_t n, int32_t *obj_id, int32_t *tri_id, double *t, double *PN, double *albedo) {
@@ -452,7 +496,7 @@ int rt_intersect_rays(rt_ctx *c, const double *rays, int64_t n, int32_t *obj_id,
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(c, RT_E_DEVICE, "rt_intersect_rays: %s", hipGetErrorString(e));
-    return RT_OK;
+    return check_overflow(c);
 }
 
 int rt_sample_radiance(rt_ctx *c, const rt_camera *cam, const rt_params *p, const int32_t *ijk, int64_t n, double *out) {
@@ -480,7 +524,7 @@ int rt_sample_radiance(rt_ctx *c, const rt_camera *cam, const rt_params *p, cons
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(c, RT_E_DEVICE, "rt_sample_radiance: %s", hipGetErrorString(e));
-    return RT_OK;
+    return check_overflow(c);
 }
 
 int rt_get_counters(rt_ctx *c, rt_counters *out) {

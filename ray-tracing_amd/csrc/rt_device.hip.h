@@ -1,21 +1,27 @@
 /*
- * rt_device.hip.h - device code of the path-tracing hot path for gfx950.
+ * rt_device.hip.h - device code of the path-tracing hot path for gfx950 (wave64).
  *
- * FP64 throughout, compiled with -ffp-contract=off: every expression keeps
- * the operation order of the reference expression it replaces (cited per
- * function), so hit parameters, hit identities and noise-free radiance equal
- * the CPU results bit for bit up to libm differences in cos/sin/log/pow.
+ * FP64 throughout, compiled with -ffp-contract=off: every expression keeps the operation order of
+ * the reference expression it replaces (cited per function), so hit parameters, hit identities and
+ * noise-free radiance equal the CPU results bit for bit up to libm differences in cos/sin/log/pow.
  *
- * Structure (one lane = one pixel, persistent over its samples):
- *   - the recursive Scene::getColor (raytracer.cpp:953-1093) becomes an
- *     iterative state machine with exactly ONE closest-hit query per loop
- *     iteration. A lane is either on a path segment or on the shadow ray of
- *     its last diffuse vertex; both kinds of ray go through the same query, so
- *     the lanes of a wave stay busy whatever mix of segments they are on, and a
- *     lane whose path ends starts its next sample at once.
- *   - radiance is carried as (sum, throughput): sum += throughput * direct,
- *     throughput *= albedo, which re-associates the reference's
- *     color += albedo * getColor(...) (raytracer.cpp:1088) by rounding only.
+ * Execution model: one workgroup = ONE wave of 64 lanes, one lane = one pixel, persistent over its
+ * samples.
+ *   - The recursive Scene::getColor (raytracer.cpp:953-1093) is an iterative state machine with
+ *     exactly one closest-hit query per loop iteration. A lane is either on a path segment or on the
+ *     shadow ray of its last diffuse vertex; both go through the same query, and a lane whose path
+ *     ends starts its next sample at once, so all lanes have a ray in (almost) every iteration.
+ *   - The closest-hit query is wave-cooperative. Spheres and the mesh root boxes are tested by each
+ *     lane for its own ray (uniform work). Every (ray, BVH record) and (ray, triangle) test after
+ *     that is an item in a pool kept in LDS; in each pool step the 64 lanes pop 64 items - whichever
+ *     rays they belong to - test them, and push the children that were hit. Lane utilisation no
+ *     longer depends on how many of the wave's rays reach a mesh or how deep each goes (a per-lane
+ *     traversal ran at 6 % VALU lane utilisation on the battle scene).
+ *   - The pool visits exactly the BVH records and triangles the reference visits (every node whose
+ *     box test passes, no pruning by distance: raytracer.cpp:652-666), in a different order. The
+ *     reference's result depends on order only through exact ties in t, where the first visited wins;
+ *     triangles are laid out in that visiting order (see rt_tri in rt_amd.h), so the tie-break is
+ *     "lowest position" and the result is order-independent.
  */
 #pragma once
 #include <hip/hip_runtime.h>
@@ -25,8 +31,12 @@
 
 namespace rtd {
 
-#define RT_STACK_MAX 64
-#define RT_LDS_SPHERES_MAX 1024
+#define RT_WAVE 64
+#define RT_LDS_SPHERES_MAX 64     /* sphere lists up to this size are staged in LDS */
+#define RT_MESH_CHUNK 16          /* meshes whose roots enter the pool together */
+#define RT_LEAF_CAP 512           /* leaf-item stack entries */
+#define RT_NODE_BITS 26           /* node index bits in a node item (the ray lane takes the top 6) */
+#define RT_MAX_DEPTH 60
 
 struct DScene {
     const rt_sphere *spheres;
@@ -38,6 +48,9 @@ struct DScene {
     const uint8_t *texels;
     const double *lut;
     int32_t n_spheres, n_meshes;
+    int32_t node_cap; /* node-item stack entries: 64 * (RT_MESH_CHUNK + max_depth + 2) */
+    int32_t pad;
+    int *overflow;    /* set to 1 if a node push would have passed node_cap */
     double I;
     double L[3];
     double lightO[3];
@@ -94,7 +107,7 @@ struct Cnt {
 };
 
 /* BoudingBox::intersect, raytracer.cpp:163-186 (six true divisions, no bound on t) */
-__device__ __forceinline__ bool box_hit(const double *b, V3 C, V3 u) {
+__device__ __noinline__ bool box_hit_exact(const double *b, V3 C, V3 u) {
     double t1x = (b[0] - C.x) / u.x, t2x = (b[3] - C.x) / u.x;
     double txMin = smin(t1x, t2x), txMax = smax(t1x, t2x);
     double t1y = (b[1] - C.y) / u.y, t2y = (b[4] - C.y) / u.y;
@@ -107,103 +120,247 @@ __device__ __forceinline__ bool box_hit(const double *b, V3 C, V3 u) {
     return tMax > tMin;
 }
 
-/* closest hit found so far, in the form that lets the attributes be computed once at the end */
+/* The same decision as box_hit_exact, bit for bit, at a third of the cost. The slab parameters are
+ * first formed with the reciprocal iu = 1/u (computed once per ray): (b - C) * iu differs from
+ * (b - C) / u by at most 3 units in the last place, and min/max are monotone, so whenever
+ * tMax and tMin are further apart than that error and tMax is not next to zero, the comparisons
+ * "tMax < 0" and "tMax > tMin" come out as with true divisions. Everything else - a zero-thickness
+ * box (tMax == tMin), a grazing ray, infinities or NaNs from a zero direction component - goes
+ * through the true divisions. */
+__device__ __forceinline__ bool box_hit(const double *b, V3 C, V3 u, V3 iu) {
+    double t1x = (b[0] - C.x) * iu.x, t2x = (b[3] - C.x) * iu.x;
+    double txMin = smin(t1x, t2x), txMax = smax(t1x, t2x);
+    double t1y = (b[1] - C.y) * iu.y, t2y = (b[4] - C.y) * iu.y;
+    double tyMin = smin(t1y, t2y), tyMax = smax(t1y, t2y);
+    double t1z = (b[2] - C.z) * iu.z, t2z = (b[5] - C.z) * iu.z;
+    double tzMin = smin(t1z, t2z), tzMax = smax(t1z, t2z);
+    double tMax = smin(txMax, smin(tyMax, tzMax));
+    double tMin = smax(txMin, smax(tyMin, tzMin));
+    double gap = fabs(tMax - tMin), mag = fabs(tMax) + fabs(tMin);
+    /* (x - x) is 0 for finite x and NaN otherwise: one test for "all six are finite" */
+    double fin = (t1x - t1x) + (t2x - t2x) + (t1y - t1y) + (t2y - t2y) + (t1z - t1z) + (t2z - t2z);
+    bool sure = (fin == 0.0) && (gap > 4e-15 * mag) && (fabs(tMax) > 1e-290);
+    if (!sure) return box_hit_exact(b, C, u);
+    return !(tMax < 0) && (tMax > tMin);
+}
+
+/* triangle test, raytracer.cpp:673-687 */
+__device__ __forceinline__ bool tri_test(const rt_tri *tr, V3 C, V3 u, double &beta, double &gamma, double &localt) {
+    V3 A = ld3(tr->A), e1 = ld3(tr->e1), e2 = ld3(tr->e2);
+    V3 N = cross(e1, e2), AO = sub(C, A), AOu = cross(AO, u);
+    double invUN = 1. / dot(u, N);
+    beta = -dot(e2, AOu) * invUN;
+    gamma = dot(e1, AOu) * invUN;
+    double alpha = 1 - beta - gamma;
+    localt = -dot(AO, N) * invUN;
+    return beta >= 0 && gamma >= 0 && beta <= 1 && gamma <= 1 && alpha >= 0 && localt > 0;
+}
+
+/* closest hit, in the form that lets the attributes be computed once at the end */
 struct HitRec {
     double t;
     int32_t obj;  /* objectId, INT32_MAX while nothing is hit */
-    int32_t prim; /* sphere index, or global permuted triangle index */
+    int32_t prim; /* sphere index, or global triangle position */
     int32_t mesh; /* mesh index or -1 for a sphere */
     double beta, gamma;
 };
 
-/* TriangleMesh::intersect traversal + triangle test, raytracer.cpp:642-692.
- * Same visiting order as the reference (the child pushed last, fd, is popped first; ascending i in
- * a leaf; strict '<' keeps the first of equal t). */
-template <bool CNT>
-__device__ __forceinline__ bool mesh_traverse(const DScene &sc, const rt_mesh &m, V3 C, V3 u, double &t_out,
-                                              int32_t &tri_out, double &beta_out, double &gamma_out, Cnt &cnt) {
-    int32_t stack_idx[RT_STACK_MAX];
-    int32_t stack_cnt[RT_STACK_MAX];
-    int sp = 0;
-    stack_idx[0] = m.root;
-    stack_cnt[0] = m.root_count;
-    sp = 1;
-    double t = 1E9;
-    int32_t tri = -1;
-    double bb = 0, gg = 0;
-    bool has_inter = false;
-    while (sp > 0) {
-        sp--;
-        int32_t idx = stack_idx[sp];
-        int32_t n = stack_cnt[sp];
-        if (n == 0) {
-            const rt_bvh_node *nd = sc.nodes + idx;
-            if (CNT) { cnt.nodes++; cnt.box_tests += 2; }
-            bool hl = box_hit(nd->boxL, C, u);
-            bool hr = box_hit(nd->boxR, C, u);
-            if (hl && sp < RT_STACK_MAX) { stack_idx[sp] = nd->L; stack_cnt[sp] = nd->nL; sp++; }
-            if (hr && sp < RT_STACK_MAX) { stack_idx[sp] = nd->R; stack_cnt[sp] = nd->nR; sp++; }
-        } else {
-            for (int32_t i = idx; i < idx + n; i++) {
-                if (CNT) cnt.tris++;
-                const rt_tri *tr = sc.tris + i;
-                V3 A = ld3(tr->A), e1 = ld3(tr->e1), e2 = ld3(tr->e2);
-                V3 N = cross(e1, e2), AO = sub(C, A), AOu = cross(AO, u);
-                double invUN = 1. / dot(u, N);
-                double beta = -dot(e2, AOu) * invUN, gamma = dot(e1, AOu) * invUN, alpha = 1 - beta - gamma,
-                       localt = -dot(AO, N) * invUN;
-                if (beta >= 0 && gamma >= 0 && beta <= 1 && gamma <= 1 && alpha >= 0 && localt > 0) {
-                    has_inter = true;
-                    if (localt < t) { t = localt; tri = i; bb = beta; gg = gamma; }
-                }
-            }
-        }
-    }
-    t_out = t; tri_out = tri; beta_out = bb; gamma_out = gg;
-    return has_inter;
+/* ---- per-wave LDS ------------------------------------------------------------------------- */
+struct WaveLDS {
+    double ray[9][RT_WAVE];               /* C, u, 1/u of each lane's ray */
+    unsigned long long best_t[RT_WAVE];   /* bits of the smallest accepted triangle t (> 0, so the bit order is the value order) */
+    int32_t best_pos[RT_WAVE];            /* lowest triangle position among those with that t */
+    uint2 leaf[RT_LEAF_CAP];              /* leaf items: x = first triangle, y = count | lane << 26 */
+    uint32_t node[1];                     /* node items: record index | lane << 26; node_cap entries, then the staged spheres */
+};
+__device__ __forceinline__ size_t wave_lds_bytes(int node_cap, int n_spheres_staged) {
+    return sizeof(WaveLDS) + (size_t)node_cap * 4 + 16 + (size_t)n_spheres_staged * sizeof(rt_sphere);
+}
+__device__ __forceinline__ const rt_sphere *lds_spheres(const WaveLDS *w, int node_cap) {
+    size_t off = (offsetof(WaveLDS, node) + (size_t)node_cap * 4 + 15) & ~(size_t)15;
+    return reinterpret_cast<const rt_sphere *>(reinterpret_cast<const unsigned char *>(w) + off);
 }
 
-/* Scene::intersect, raytracer.cpp:930-951, over spheres (Sphere::intersect :883-918) and meshes.
- * Objects are visited spheres first, then meshes; "lowest objectId wins an exact tie" is what the
- * reference's in-order loop with strict '<' produces, and is applied explicitly here. */
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ int rank_in(unsigned long long mask) { /* set bits below this lane */
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+/* Orders this wave's LDS accesses for the compiler. A wave's LDS instructions execute in program
+ * order, so no hardware barrier is needed between the lanes of one wave (workgroup = one wave). */
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+/* Scene::intersect, raytracer.cpp:930-951. Called by all 64 lanes together; `active` lanes get the
+ * closest hit of their ray (C, u). */
 template <bool CNT>
-__device__ __forceinline__ bool scene_closest(const DScene &sc, const rt_sphere *sph, V3 C, V3 u, HitRec &h, Cnt &cnt) {
-    if (CNT) cnt.rays++;
+__device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w, const rt_sphere *sph, bool active, V3 C, V3 u,
+                                                   HitRec &h, Cnt &cnt) {
+    const int lane = lane_id();
     h.t = 1E10;
     h.obj = INT32_MAX;
     h.prim = -1;
     h.mesh = -1;
     h.beta = h.gamma = 0;
-    for (int s = 0; s < sc.n_spheres; s++) {
-        V3 O = ld3(sph[s].O);
-        double R = sph[s].R;
-        int32_t oid = sph[s].object_id;
-        double a = 1;
-        V3 CO = sub(C, O);
-        double b = 2 * dot(u, CO);
-        double c = norm2(CO) - R * R;
-        double delta = b * b - 4 * a * c;
-        if (delta < 0) continue;
-        double sq = sqrt(delta);
-        double t2 = (-b + sq) / (2 * a);
-        if (t2 < 0) continue;
-        double t1 = (-b - sq) / (2 * a);
-        double t = (t1 > 0) ? t1 : t2;
-        if (t < h.t || (t == h.t && oid < h.obj)) { h.t = t; h.obj = oid; h.prim = s; h.mesh = -1; }
-    }
-    for (int mi = 0; mi < sc.n_meshes; mi++) {
-        const rt_mesh &m = sc.meshes[mi];
-        if (CNT) cnt.box_tests++;
-        if (!box_hit(m.root_box, C, u)) continue;
-        if (CNT) cnt.mesh_calls++;
-        double t, bb, gg;
-        int32_t tri;
-        bool ok = mesh_traverse<CNT>(sc, m, C, u, t, tri, bb, gg, cnt);
-        /* ok with tri < 0 needs an accepted triangle with t >= 1e9 (raytracer.cpp:689-690); not a usable hit */
-        if (ok && tri >= 0 && (t < h.t || (t == h.t && m.object_id < h.obj))) {
-            h.t = t; h.obj = m.object_id; h.prim = tri; h.mesh = mi; h.beta = bb; h.gamma = gg;
+    /* spheres: Sphere::intersect, raytracer.cpp:883-918; the lowest objectId wins an exact tie (:938) */
+    if (active) {
+        if (CNT) cnt.rays++;
+        for (int s = 0; s < sc.n_spheres; s++) {
+            V3 O = ld3(sph[s].O);
+            double R = sph[s].R;
+            int32_t oid = sph[s].object_id;
+            double a = 1;
+            V3 CO = sub(C, O);
+            double b = 2 * dot(u, CO);
+            double c = norm2(CO) - R * R;
+            double delta = b * b - 4 * a * c;
+            if (delta < 0) continue;
+            double sq = sqrt(delta);
+            double t2 = (-b + sq) / (2 * a);
+            if (t2 < 0) continue;
+            double t1 = (-b - sq) / (2 * a);
+            double t = (t1 > 0) ? t1 : t2;
+            if (t < h.t || (t == h.t && oid < h.obj)) { h.t = t; h.obj = oid; h.prim = s; h.mesh = -1; }
         }
     }
+    if (sc.n_meshes == 0) return h.obj != INT32_MAX;
+
+    V3 iu = mk(1.0 / u.x, 1.0 / u.y, 1.0 / u.z);
+    w->ray[0][lane] = C.x; w->ray[1][lane] = C.y; w->ray[2][lane] = C.z;
+    w->ray[3][lane] = u.x; w->ray[4][lane] = u.y; w->ray[5][lane] = u.z;
+    w->ray[6][lane] = iu.x; w->ray[7][lane] = iu.y; w->ray[8][lane] = iu.z;
+    w->best_t[lane] = (unsigned long long)__double_as_longlong(1E9); /* t = 1E9 before the first triangle, :647 */
+    w->best_pos[lane] = INT32_MAX;
+
+    int n_nodes = 0, n_leaves = 0; /* wave-uniform stack heights */
+    int mi = 0;
+    while (mi < sc.n_meshes) {
+        /* root boxes (raytracer.cpp:644): every lane for its own ray; roots that pass enter the pool.
+         * Roots are fed in groups small enough for the stacks (at most RT_MESH_CHUNK meshes). */
+        const int root_budget = RT_WAVE * RT_MESH_CHUNK;
+        while (mi < sc.n_meshes && n_nodes + RT_WAVE <= root_budget && n_leaves + 4 * RT_WAVE <= RT_LEAF_CAP) {
+            const rt_mesh &m = sc.meshes[mi];
+            mi++;
+            bool pass = false;
+            if (active) {
+                if (CNT) cnt.box_tests++;
+                pass = box_hit(m.root_box, C, u, iu);
+                if (CNT && pass) cnt.mesh_calls++;
+            }
+            const unsigned long long bal = __ballot(pass);
+            if (bal == 0ull) continue;
+            const int r = rank_in(bal);
+            if (m.root_count == 0) {
+                if (pass) w->node[n_nodes + r] = (uint32_t)m.root | ((uint32_t)lane << RT_NODE_BITS);
+                n_nodes = uni(n_nodes + __popcll(bal));
+            } else { /* the root is itself a leaf */
+                if (pass) w->leaf[n_leaves + r] = make_uint2((uint32_t)m.root, (uint32_t)m.root_count | ((uint32_t)lane << 26));
+                n_leaves = uni(n_leaves + __popcll(bal));
+            }
+        }
+        wave_sync();
+        /* pool: until both stacks are empty, up to 64 items per step */
+        while (n_nodes + n_leaves > 0) {
+            const bool do_leaf = (n_leaves >= RT_WAVE) || (n_nodes == 0) || (n_leaves + 2 * RT_WAVE > RT_LEAF_CAP);
+            if (do_leaf) {
+                /* one triangle per lane: pop (first, count), test `first`, push back (first+1, count-1) */
+                const int k = n_leaves < RT_WAVE ? n_leaves : RT_WAVE;
+                const bool have = lane < k;
+                uint2 it = make_uint2(0u, 0u);
+                if (have) it = w->leaf[n_leaves - 1 - lane];
+                n_leaves -= k;
+                wave_sync();
+                const int rl = (int)(it.y >> 26);
+                const uint32_t count = it.y & 0x3FFFFFFu;
+                bool acc = false;
+                double beta, gamma, lt = 0;
+                if (have) {
+                    if (CNT) cnt.tris++;
+                    V3 rc = mk(w->ray[0][rl], w->ray[1][rl], w->ray[2][rl]);
+                    V3 ru = mk(w->ray[3][rl], w->ray[4][rl], w->ray[5][rl]);
+                    acc = tri_test(sc.tris + it.x, rc, ru, beta, gamma, lt) && (lt < 1E9);
+                }
+                const bool more = have && count > 1u;
+                const unsigned long long bm = __ballot(more);
+                if (more) w->leaf[n_leaves + rank_in(bm)] = make_uint2(it.x + 1u, (count - 1u) | ((uint32_t)rl << 26));
+                n_leaves = uni(n_leaves + __popcll(bm));
+                if (__ballot(acc) != 0ull) {
+                    /* keep (min t, then min position) per ray. LDS executes one wave's instructions in
+                     * order, so every lane's atomic of one statement is done before the next statement's
+                     * reads: no barrier is needed inside a wave, only the compiler must keep the order. */
+                    const unsigned long long tb = (unsigned long long)__double_as_longlong(lt);
+                    unsigned long long old = 0;
+                    if (acc) old = atomicMin(&w->best_t[rl], tb);
+                    wave_sync();
+                    bool mine = false;
+                    if (acc) {
+                        const unsigned long long cur = w->best_t[rl];
+                        mine = (tb == cur);
+                        if (mine && old > cur) w->best_pos[rl] = INT32_MAX; /* this lane lowered the minimum */
+                    }
+                    wave_sync();
+                    if (mine) atomicMin(&w->best_pos[rl], (int32_t)it.x);
+                }
+                wave_sync();
+            } else {
+                /* one BVH record per lane: test both child boxes (raytracer.cpp:656-665), push the hit ones */
+                const int k = n_nodes < RT_WAVE ? n_nodes : RT_WAVE;
+                const bool have = lane < k;
+                uint32_t it = 0;
+                if (have) it = w->node[n_nodes - 1 - lane];
+                n_nodes -= k;
+                wave_sync();
+                const int rl = (int)(it >> RT_NODE_BITS);
+                bool pnl = false, pnr = false, pll = false, plr = false;
+                int32_t L = 0, R = 0, nL = 0, nR = 0;
+                if (have) {
+                    const rt_bvh_node *nd = sc.nodes + (it & ((1u << RT_NODE_BITS) - 1u));
+                    if (CNT) { cnt.nodes++; cnt.box_tests += 2; }
+                    V3 rc = mk(w->ray[0][rl], w->ray[1][rl], w->ray[2][rl]);
+                    V3 ru = mk(w->ray[3][rl], w->ray[4][rl], w->ray[5][rl]);
+                    V3 ri = mk(w->ray[6][rl], w->ray[7][rl], w->ray[8][rl]);
+                    L = nd->L; R = nd->R; nL = nd->nL; nR = nd->nR;
+                    const bool hl = box_hit(nd->boxL, rc, ru, ri);
+                    const bool hr = box_hit(nd->boxR, rc, ru, ri);
+                    pnl = hl && nL == 0; pll = hl && nL > 0;
+                    pnr = hr && nR == 0; plr = hr && nR > 0;
+                }
+                const unsigned long long b0 = __ballot(pnl), b1 = __ballot(pnr), b2 = __ballot(pll), b3 = __ballot(plr);
+                const int c0 = __popcll(b0), c1 = __popcll(b1);
+                if (n_nodes + c0 + c1 > sc.node_cap) { /* cannot happen for a validated scene; never write past the stack */
+                    if (lane == 0) atomicOr(sc.overflow, 1);
+                    pnl = pnr = false;
+                } else {
+                    if (pnl) w->node[n_nodes + rank_in(b0)] = (uint32_t)L | ((uint32_t)rl << RT_NODE_BITS);
+                    if (pnr) w->node[n_nodes + c0 + rank_in(b1)] = (uint32_t)R | ((uint32_t)rl << RT_NODE_BITS);
+                    n_nodes = uni(n_nodes + c0 + c1);
+                }
+                const int c2 = __popcll(b2);
+                if (pll) w->leaf[n_leaves + rank_in(b2)] = make_uint2((uint32_t)L, (uint32_t)nL | ((uint32_t)rl << 26));
+                if (plr) w->leaf[n_leaves + c2 + rank_in(b3)] = make_uint2((uint32_t)R, (uint32_t)nR | ((uint32_t)rl << 26));
+                n_leaves = uni(n_leaves + c2 + __popcll(b3));
+                wave_sync();
+            }
+        }
+    }
+    /* the mesh hit of this lane's ray, and Scene::intersect's choice between it and the sphere hit */
+    if (active) {
+        const double tm = __longlong_as_double((long long)w->best_t[lane]);
+        const int32_t pos = w->best_pos[lane];
+        if (tm < 1E9 && pos != INT32_MAX) {
+            const int32_t mi = sc.tris[pos].mesh;
+            const int32_t oid = sc.meshes[mi].object_id;
+            if (tm < h.t || (tm == h.t && oid < h.obj)) {
+                h.t = tm; h.obj = oid; h.prim = pos; h.mesh = mi;
+                double lt;
+                (void)tri_test(sc.tris + pos, C, u, h.beta, h.gamma, lt); /* alpha, beta, gamma of the winner (:683-685) */
+            }
+        }
+    }
+    wave_sync();
     return h.obj != INT32_MAX;
 }
 
@@ -271,11 +428,12 @@ struct RenderArgs {
     int32_t j0, i0, j1, i1;
 };
 
-/* Sum of the radiance of samples k0 .. k0+nk-1 of pixel (i, j), added in that order
- * (the k loop of raytracer.cpp:1464-1486). */
+/* Sum of the radiance of samples k0 .. k0+nk-1 of pixel (i, j), added in that order (the k loop of
+ * raytracer.cpp:1464-1486). Called by all 64 lanes of the wave; lanes with live == false only help
+ * in the pool. */
 template <bool CNT>
-__device__ __forceinline__ V3 trace_pixel(const DScene &sc, const rt_sphere *sph, const RenderArgs &ra, int i, int j,
-                                          int k0, int nk, Cnt &cnt) {
+__device__ __forceinline__ V3 trace_pixel(const DScene &sc, WaveLDS *w, const rt_sphere *sph, const RenderArgs &ra, bool live, int i,
+                                          int j, int k0, int nk, Cnt &cnt) {
     const rt_params &p = ra.p;
     const rt_camera &cam = ra.cam;
     const uint32_t fl = p.flags;
@@ -288,12 +446,12 @@ __device__ __forceinline__ V3 trace_pixel(const DScene &sc, const rt_sphere *sph
 
     V3 acc = mk(0, 0, 0);
     int k = k0;
-    const int kend = k0 + nk;
+    const int kend = live ? k0 + nk : k0;
 
     /* per-path state */
     uint64_t key = 0;
     uint32_t ctr = 0;
-    V3 rC = mk(0, 0, 0), ru = mk(0, 0, 0); /* ray being traced */
+    V3 rC = mk(0, 0, 0), ru = mk(0, 0, 1); /* ray being traced */
     V3 Lsum = mk(0, 0, 0), T = mk(1, 1, 1);
     int rebond = 0;
     bool lastDiffuse = false;
@@ -302,43 +460,49 @@ __device__ __forceinline__ V3 trace_pixel(const DScene &sc, const rt_sphere *sph
     V3 nee = mk(0, 0, 0), nextC = mk(0, 0, 0), nextU = mk(0, 0, 0), vAlbedo = mk(0, 0, 0);
     double sh_limit = 0;
     bool fresh = true;
+    bool finished = false;
 
     while (true) {
-        if (fresh) {
-            if (k >= kend) break;
-            if (CNT) cnt.paths++;
-            key = rng_key(ra.seed_mixed, pixel, (uint32_t)k);
-            ctr = 0;
-            if (fl & RT_F_NO_JITTER) { /* Ray r(C, u), raytracer.cpp:1482 */
-                V3 d = mk(j - p.W / 2 + 0.5, i - p.H / 2 + 0.5, cam.zdist);
-                d = unit(d);
-                ru = add(add(smul(d.x, right), smul(d.y, up)), smul(d.z, view));
-                rC = camC;
-            } else { /* raytracer.cpp:1467-1483 */
-                double u1 = rng_uniform(key, 0), u2 = rng_uniform(key, 1);
-                double x1 = cam.aa_sigma * cos(2 * RT_PI * u1) * sqrt(-2 * log(u2)),
-                       x2 = cam.aa_sigma * sin(2 * RT_PI * u1) * sqrt(-2 * log(u2));
-                double u3 = rng_uniform(key, 2), u4 = rng_uniform(key, 3);
-                double x3 = cam.dof_sigma * cos(2 * RT_PI * u3) * sqrt(-2 * log(u4)),
-                       x4 = cam.dof_sigma * sin(2 * RT_PI * u3) * sqrt(-2 * log(u4));
-                ctr = 4;
-                V3 d = mk(j - p.W / 2 + x2 + 0.5, i - p.H / 2 + x1 + 0.5, cam.zdist);
-                d = unit(d);
-                d = add(add(smul(d.x, right), smul(d.y, up)), smul(d.z, view));
-                V3 target = add(camC, smul(cam.focus, d));
-                rC = add(camC, mk(x3, x4, 0));
-                ru = unit(sub(target, rC));
+        if (fresh && !finished) {
+            if (k >= kend) {
+                finished = true;
+            } else {
+                if (CNT) cnt.paths++;
+                key = rng_key(ra.seed_mixed, pixel, (uint32_t)k);
+                ctr = 0;
+                if (fl & RT_F_NO_JITTER) { /* Ray r(C, u), raytracer.cpp:1482 */
+                    V3 d = mk(j - p.W / 2 + 0.5, i - p.H / 2 + 0.5, cam.zdist);
+                    d = unit(d);
+                    ru = add(add(smul(d.x, right), smul(d.y, up)), smul(d.z, view));
+                    rC = camC;
+                } else { /* raytracer.cpp:1467-1483 */
+                    double u1 = rng_uniform(key, 0), u2 = rng_uniform(key, 1);
+                    double x1 = cam.aa_sigma * cos(2 * RT_PI * u1) * sqrt(-2 * log(u2)),
+                           x2 = cam.aa_sigma * sin(2 * RT_PI * u1) * sqrt(-2 * log(u2));
+                    double u3 = rng_uniform(key, 2), u4 = rng_uniform(key, 3);
+                    double x3 = cam.dof_sigma * cos(2 * RT_PI * u3) * sqrt(-2 * log(u4)),
+                           x4 = cam.dof_sigma * sin(2 * RT_PI * u3) * sqrt(-2 * log(u4));
+                    ctr = 4;
+                    V3 d = mk(j - p.W / 2 + x2 + 0.5, i - p.H / 2 + x1 + 0.5, cam.zdist);
+                    d = unit(d);
+                    d = add(add(smul(d.x, right), smul(d.y, up)), smul(d.z, view));
+                    V3 target = add(camC, smul(cam.focus, d));
+                    rC = add(camC, mk(x3, x4, 0));
+                    ru = unit(sub(target, rC));
+                }
+                Lsum = mk(0, 0, 0);
+                T = mk(1, 1, 1);
+                rebond = 0;
+                lastDiffuse = false;
+                shadow = false;
+                fresh = false;
             }
-            Lsum = mk(0, 0, 0);
-            T = mk(1, 1, 1);
-            rebond = 0;
-            lastDiffuse = false;
-            shadow = false;
-            fresh = false;
         }
+        if (__ballot(!finished) == 0ull) break;
 
         HitRec h;
-        bool inter = scene_closest<CNT>(sc, sph, rC, ru, h, cnt);
+        bool inter = scene_closest_wave<CNT>(sc, w, sph, !finished, rC, ru, h, cnt);
+        if (finished) continue;
 
         if (shadow) {
             /* raytracer.cpp:1073-1083 (or :1048-1055 for the point light): occluded iff hit before the light */
@@ -426,15 +590,15 @@ __device__ __forceinline__ V3 trace_pixel(const DScene &sc, const rt_sphere *sph
                     V3 PL = unit(sub(Lpos, P));
                     double u1 = rng_uniform(key, ctr), u2 = rng_uniform(key, ctr + 1);
                     ctr += 2;
-                    V3 w = random_cos(u1, u2, neg(PL));
-                    V3 xprime = add(muls(w, lightR), lightO);
+                    V3 wv = random_cos(u1, u2, neg(PL));
+                    V3 xprime = add(muls(wv, lightR), lightO);
                     V3 Px = sub(xprime, P);
                     double d = sqrt(norm2(Px));
                     Px = divs(Px, d);
                     shU = Px;
                     double R2 = sqr(lightR);
-                    double proba = smax(1E-8, dot(neg(PL), w)) / (RT_PI * R2);
-                    double J = smax(0., dot(w, neg(Px))) / (d * d);
+                    double proba = smax(1E-8, dot(neg(PL), wv)) / (RT_PI * R2);
+                    double J = smax(0., dot(wv, neg(Px))) / (d * d);
                     nee = divs(muls(muls(smul(sc.I / (4 * RT_PI * RT_PI * R2), divs(s.albedo, RT_PI)), smax(0., dot(N, Px))), J), proba);
                     sh_limit = d - p.shadow_bias;
                 }

@@ -10,6 +10,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 namespace rt {
 
 static const double kPi = 3.14159265358979323846;
@@ -368,16 +370,37 @@ void flatten(const Scene &scene, FlatScene &out) {
         rm.first_tex = (int32_t)out.tex.size();
         rm.n_tex = (int32_t)m->textures.size();
         rm.max_depth = m->maxDepth();
-        /* triangles in BVH order: A, e1 = B - A, e2 = C - A (:673-677) and the gathered attributes */
+        /* Triangle order in HBM = the order in which the reference's traversal would VISIT them if it
+         * visited everything: it pops fd before fg (raytracer.cpp:656-665), so leaves come in descending
+         * `debut`, and a leaf is scanned in ascending i (:670). With this layout "the first visited of
+         * equal t wins" (strict '<' at :690) is "the lower position wins", whatever order the GPU
+         * traverses in. */
+        std::vector<int> leaf_new_first(m->indices.size() + 1, -1);
+        std::vector<int> visit; /* visit[new position - first_tri] = position in m->indices */
+        visit.reserve(m->indices.size());
+        {
+            std::vector<int> leaves;
+            for (size_t k = 0; k < m->bvh.size(); k++) if (m->bvh[k].fg < 0) leaves.push_back((int)k);
+            std::sort(leaves.begin(), leaves.end(), [&](int x, int y) { return m->bvh[x].debut > m->bvh[y].debut; });
+            for (size_t q = 0; q < leaves.size(); q++) {
+                const BVHNode &lf = m->bvh[(size_t)leaves[q]];
+                leaf_new_first[(size_t)lf.debut] = rm.first_tri + (int)visit.size();
+                for (int i = lf.debut; i < lf.fin; i++) visit.push_back(i);
+            }
+        }
+        if (visit.size() != m->indices.size()) throw std::runtime_error("flatten: BVH leaves do not cover the triangles");
+        /* A, e1 = B - A, e2 = C - A (:673-677) and the gathered attributes */
         const int nn = (int)m->normals.size(), nuv = (int)m->uvs.size();
-        for (size_t k = 0; k < m->indices.size(); k++) {
+        const int32_t mesh_index = (int32_t)out.meshes.size();
+        for (size_t vk = 0; vk < visit.size(); vk++) {
+            const size_t k = (size_t)visit[vk];
             const TriangleIndices &t = m->indices[k];
             const Vector &A = m->vertices[t.vtxi], &B = m->vertices[t.vtxj], &C = m->vertices[t.vtxk];
             Vector e1 = B - A, e2 = C - A;
             rt_tri rt_;
             for (int q = 0; q < 3; q++) { rt_.A[q] = A[q]; rt_.e1[q] = e1[q]; rt_.e2[q] = e2[q]; }
             rt_.orig_id = m->order[k];
-            rt_.pad = 0;
+            rt_.mesh = mesh_index;
             out.tris.push_back(rt_);
             rt_tri_attr at;
             memset(&at, 0, sizeof at);
@@ -399,7 +422,7 @@ void flatten(const Scene &scene, FlatScene &out) {
         }
         /* nodes: one record per inner Noeud holding both child boxes; children get larger indices */
         if (m->bvh[0].fg < 0) {
-            rm.root = rm.first_tri + m->bvh[0].debut;
+            rm.root = leaf_new_first[(size_t)m->bvh[0].debut];
             rm.root_count = m->bvh[0].fin - m->bvh[0].debut;
         } else {
             std::vector<int> rec_of(m->bvh.size(), -1);
@@ -414,8 +437,8 @@ void flatten(const Scene &scene, FlatScene &out) {
                 memset(&r, 0, sizeof r);
                 const BVHNode &a = m->bvh[n.fg], &b = m->bvh[n.fd];
                 for (int q = 0; q < 6; q++) { r.boxL[q] = a.box[q]; r.boxR[q] = b.box[q]; }
-                if (a.fg >= 0) { r.L = rec_of[n.fg]; r.nL = 0; } else { r.L = rm.first_tri + a.debut; r.nL = a.fin - a.debut; }
-                if (b.fg >= 0) { r.R = rec_of[n.fd]; r.nR = 0; } else { r.R = rm.first_tri + b.debut; r.nR = b.fin - b.debut; }
+                if (a.fg >= 0) { r.L = rec_of[n.fg]; r.nL = 0; } else { r.L = leaf_new_first[(size_t)a.debut]; r.nL = a.fin - a.debut; }
+                if (b.fg >= 0) { r.R = rec_of[n.fd]; r.nR = 0; } else { r.R = leaf_new_first[(size_t)b.debut]; r.nR = b.fin - b.debut; }
             }
             rm.root = rec_of[0];
             rm.root_count = 0;
