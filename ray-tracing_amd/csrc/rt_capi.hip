@@ -16,6 +16,7 @@
 
 using namespace rtd;
 
+#define RT_COUNTER_WORDS 20 /* rt_counters (8 words) + 12 diagnostic words of rt_device.hip.h */
 #define RT_BLOCK 64 /* one workgroup = one wave: the LDS pool of rt_device.hip.h is per wave */
 
 /* ---------------------------------------------------------------------------------------------
@@ -61,7 +62,7 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_render_kernel(DScene sc, RenderAr
     WaveLDS *w = wave_setup(sc, lds_raw, &sph);
     int i, j;
     const bool live = lane_pixel(ra, i, j);
-    Cnt cnt = {0, 0, 0, 0, 0, 0, 0, 0};
+    Cnt cnt = {};
     V3 a = trace_pixel<CNT>(sc, w, sph, ra, live, i, j, k0, nk, cnt);
     if (live) {
         double *px = accum + ((int64_t)i * ra.p.W + j) * 3;
@@ -80,7 +81,7 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_sample_kernel(DScene sc, RenderAr
     WaveLDS *w = wave_setup(sc, lds_raw, &sph);
     const int64_t q = (int64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
     const bool live = q < n;
-    Cnt cnt = {0, 0, 0, 0, 0, 0, 0, 0};
+    Cnt cnt = {};
     const int i = live ? ijk[3 * q] : 0, j = live ? ijk[3 * q + 1] : 0, k = live ? ijk[3 * q + 2] : 0;
     V3 a = trace_pixel<false>(sc, w, sph, ra, live, i, j, k, 1, cnt);
     if (live) {
@@ -101,7 +102,7 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_intersect_kernel(DScene sc, const
     V3 C = mk(0, 0, 0), u = mk(0, 0, 1);
     if (live) { C = ld3(rays + 6 * q); u = ld3(rays + 6 * q + 3); }
     HitRec h;
-    Cnt cnt = {0, 0, 0, 0, 0, 0, 0, 0};
+    Cnt cnt = {};
     bool ok = scene_closest_wave<false>(sc, w, sph, live, C, u, h, cnt);
     if (!live) return;
     obj_id[q] = ok ? h.obj : -1;
@@ -114,6 +115,13 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_intersect_kernel(DScene sc, const
     PN[6 * q] = s.P.x; PN[6 * q + 1] = s.P.y; PN[6 * q + 2] = s.P.z;
     PN[6 * q + 3] = s.N.x; PN[6 * q + 4] = s.N.y; PN[6 * q + 5] = s.N.z;
     albedo[3 * q] = s.albedo.x; albedo[3 * q + 1] = s.albedo.y; albedo[3 * q + 2] = s.albedo.z;
+}
+
+/* self-test of the DPP wave scans used by the triangle step */
+__global__ void __launch_bounds__(RT_BLOCK) rt_scan_test_kernel(const int *in, int *out_add, int *out_max) {
+    const int v = in[threadIdx.x];
+    out_add[threadIdx.x] = wave_scan_add(v);
+    out_max[threadIdx.x] = wave_scan_max(v);
 }
 
 /* raytracer.cpp:1488-1501: /nbrays, pow 0.45, min(255, .), truncation to u8, row flip */
@@ -219,8 +227,8 @@ int rt_create(int device, rt_ctx **out) {
     c->device = device;
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
-        (e = hipMalloc((void **)&c->d_counters, sizeof(rt_counters))) != hipSuccess ||
-        (e = hipMemset(c->d_counters, 0, sizeof(rt_counters))) != hipSuccess ||
+        (e = hipMalloc((void **)&c->d_counters, RT_COUNTER_WORDS * 8)) != hipSuccess ||
+        (e = hipMemset(c->d_counters, 0, RT_COUNTER_WORDS * 8)) != hipSuccess ||
         (e = hipMalloc((void **)&c->d_overflow, sizeof(int))) != hipSuccess || (e = hipMemset(c->d_overflow, 0, sizeof(int))) != hipSuccess) {
         fail(nullptr, RT_E_DEVICE, "rt_create: %s", hipGetErrorString(e));
         delete c;
@@ -535,10 +543,39 @@ int rt_get_counters(rt_ctx *c, rt_counters *out) {
     return RT_OK;
 }
 
+/* not part of the public header: 12 diagnostic words of the counted kernel variant (cycle stamps per
+ * phase and pool occupancy), for tools/ only */
+int rt_debug_stats(rt_ctx *c, uint64_t *out12) {
+    if (!c || !out12) return RT_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out12, reinterpret_cast<uint64_t *>(c->d_counters) + 8, 12 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+/* not part of the public header: runs the wave-scan self-test on 64 ints (tests/ only) */
+int rt_debug_wave_scan(rt_ctx *c, const int32_t *in64, int32_t *add64, int32_t *max64) {
+    if (!c || !in64 || !add64 || !max64) return RT_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    int *d = nullptr;
+    if (hipMalloc((void **)&d, 3 * 64 * sizeof(int)) != hipSuccess) return fail(c, RT_E_NOMEM, "allocation failed");
+    hipError_t e = hipMemcpyAsync(d, in64, 64 * sizeof(int), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rt_scan_test_kernel, dim3(1), dim3(RT_BLOCK), 0, c->stream, d, d + 64, d + 128);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(add64, d + 64, 64 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(max64, d + 128, 64 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, RT_E_DEVICE, "rt_debug_wave_scan: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
 int rt_reset_counters(rt_ctx *c) {
     if (!c) return RT_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(rt_counters), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, RT_COUNTER_WORDS * 8, c->stream));
     return RT_OK;
 }
 

@@ -35,6 +35,7 @@ namespace rtd {
 #define RT_LDS_SPHERES_MAX 64     /* sphere lists up to this size are staged in LDS */
 #define RT_MESH_CHUNK 16          /* meshes whose roots enter the pool together */
 #define RT_LEAF_CAP 512           /* leaf-item stack entries */
+#define RT_LEAF_TRIGGER 24        /* pending leaf items that make the next pool step a triangle step */
 #define RT_NODE_BITS 26           /* node index bits in a node item (the ray lane takes the top 6) */
 #define RT_MAX_DEPTH 60
 
@@ -104,7 +105,11 @@ __device__ __forceinline__ double rng_uniform(uint64_t key, uint32_t n) {
 
 struct Cnt {
     uint64_t paths, rays, box_tests, nodes, tris, mesh_calls, diffuse, specular;
+    /* diagnostic build only (RT_F_COUNTERS): wave-level cycle stamps and pool occupancy */
+    uint64_t cyc_fresh, cyc_roots, cyc_node, cyc_leaf, cyc_finish, cyc_shade;
+    uint64_t node_steps, node_lanes, leaf_steps, leaf_lanes, queries, query_lanes;
 };
+#define RT_STAMP() ((uint64_t)__builtin_amdgcn_s_memtime())
 
 /* BoudingBox::intersect, raytracer.cpp:163-186 (six true divisions, no bound on t) */
 __device__ __noinline__ bool box_hit_exact(const double *b, V3 C, V3 u) {
@@ -170,6 +175,8 @@ struct WaveLDS {
     double ray[9][RT_WAVE];               /* C, u, 1/u of each lane's ray */
     unsigned long long best_t[RT_WAVE];   /* bits of the smallest accepted triangle t (> 0, so the bit order is the value order) */
     int32_t best_pos[RT_WAVE];            /* lowest triangle position among those with that t */
+    int32_t mark[RT_WAVE];                /* triangle step: slot -> leaf item that starts there, or -1 */
+    int32_t ex[RT_WAVE];                  /* triangle step: first slot of each leaf item */
     uint2 leaf[RT_LEAF_CAP];              /* leaf items: x = first triangle, y = count | lane << 26 */
     uint32_t node[1];                     /* node items: record index | lane << 26; node_cap entries, then the staged spheres */
 };
@@ -186,6 +193,31 @@ __device__ __forceinline__ int rank_in(unsigned long long mask) { /* set bits be
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+/* inclusive scans over the 64 lanes with DPP row shifts / row broadcasts (no LDS) */
+#define RT_DPP(old, src, ctrl, rmask, bmask) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rmask), (bmask), false)
+__device__ __forceinline__ int wave_scan_add(int v) {
+    int x = v;
+    x += RT_DPP(0, v, 0x111, 0xf, 0xf); /* row_shr:1 */
+    x += RT_DPP(0, v, 0x112, 0xf, 0xf); /* row_shr:2 */
+    x += RT_DPP(0, v, 0x113, 0xf, 0xf); /* row_shr:3 */
+    x += RT_DPP(0, x, 0x114, 0xf, 0xe); /* row_shr:4, banks 1-3 */
+    x += RT_DPP(0, x, 0x118, 0xf, 0xc); /* row_shr:8, banks 2-3 */
+    x += RT_DPP(0, x, 0x142, 0xa, 0xf); /* row_bcast:15 into rows 1 and 3 */
+    x += RT_DPP(0, x, 0x143, 0xc, 0xf); /* row_bcast:31 into rows 2 and 3 */
+    return x;
+}
+__device__ __forceinline__ int wave_scan_max(int v) {
+    int x = v, t;
+    t = RT_DPP(-1, v, 0x111, 0xf, 0xf); x = t > x ? t : x;
+    t = RT_DPP(-1, v, 0x112, 0xf, 0xf); x = t > x ? t : x;
+    t = RT_DPP(-1, v, 0x113, 0xf, 0xf); x = t > x ? t : x;
+    t = RT_DPP(-1, x, 0x114, 0xf, 0xe); x = t > x ? t : x;
+    t = RT_DPP(-1, x, 0x118, 0xf, 0xc); x = t > x ? t : x;
+    t = RT_DPP(-1, x, 0x142, 0xa, 0xf); x = t > x ? t : x;
+    t = RT_DPP(-1, x, 0x143, 0xc, 0xf); x = t > x ? t : x;
+    return x;
+}
+
 /* Orders this wave's LDS accesses for the compiler. A wave's LDS instructions execute in program
  * order, so no hardware barrier is needed between the lanes of one wave (workgroup = one wave). */
 __device__ __forceinline__ void wave_sync() {
@@ -205,6 +237,8 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
     h.prim = -1;
     h.mesh = -1;
     h.beta = h.gamma = 0;
+    uint64_t st0 = 0;
+    if (CNT) { st0 = RT_STAMP(); cnt.queries++; cnt.query_lanes += (uint64_t)__popcll(__ballot(active)); }
     /* spheres: Sphere::intersect, raytracer.cpp:883-918; the lowest objectId wins an exact tie (:938) */
     if (active) {
         if (CNT) cnt.rays++;
@@ -262,31 +296,51 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
             }
         }
         wave_sync();
+        if (CNT) { uint64_t t = RT_STAMP(); cnt.cyc_roots += t - st0; st0 = t; }
         /* pool: until both stacks are empty, up to 64 items per step */
         while (n_nodes + n_leaves > 0) {
-            const bool do_leaf = (n_leaves >= RT_WAVE) || (n_nodes == 0) || (n_leaves + 2 * RT_WAVE > RT_LEAF_CAP);
+            const bool do_leaf = (n_leaves >= RT_LEAF_TRIGGER) || (n_nodes == 0) || (n_leaves + 2 * RT_WAVE > RT_LEAF_CAP);
             if (do_leaf) {
-                /* one triangle per lane: pop (first, count), test `first`, push back (first+1, count-1) */
-                const int k = n_leaves < RT_WAVE ? n_leaves : RT_WAVE;
-                const bool have = lane < k;
+                /* 64 triangles per step whichever leaves they sit in: the top m <= 64 leaf items are
+                 * (first, count) ranges; a prefix sum of the counts gives every item its slots, slot s (=
+                 * lane s) finds its item through a marker + running maximum, and tests triangle
+                 * first + (s - first slot of the item). Items used up are popped, the one cut by slot 64 is
+                 * shortened in place and becomes the new top. */
+                const int m = n_leaves < RT_WAVE ? n_leaves : RT_WAVE;
                 uint2 it = make_uint2(0u, 0u);
-                if (have) it = w->leaf[n_leaves - 1 - lane];
-                n_leaves -= k;
+                if (lane < m) it = w->leaf[n_leaves - 1 - lane];
+                const int cntl = (lane < m) ? (int)(it.y & 0x3FFFFFFu) : 0;
+                const int incl = wave_scan_add(cntl);
+                const int excl = incl - cntl;
+                const int total = __builtin_amdgcn_readlane(incl, 63);
+                const int take = total < RT_WAVE ? total : RT_WAVE;
+                w->mark[lane] = -1;
                 wave_sync();
-                const int rl = (int)(it.y >> 26);
-                const uint32_t count = it.y & 0x3FFFFFFu;
+                if (lane < m && excl < RT_WAVE) w->mark[excl] = lane;
+                w->ex[lane] = excl;
+                wave_sync();
+                const int j = wave_scan_max(w->mark[lane]);
+                const bool have = lane < take; /* then j >= 0: slot 0 carries the marker of item 0 */
+                uint2 itj = make_uint2(0u, 0u);
+                int exj = 0;
+                if (have) { itj = w->leaf[n_leaves - 1 - j]; exj = w->ex[j]; }
+                const uint32_t tri = itj.x + (uint32_t)(lane - exj);
+                const int rl = (int)(itj.y >> 26);
+                wave_sync();
+                if (lane < m && excl < RT_WAVE && incl > RT_WAVE) { /* the item cut by the last slot */
+                    const uint32_t used = (uint32_t)(RT_WAVE - excl);
+                    w->leaf[n_leaves - 1 - lane] = make_uint2(it.x + used, ((uint32_t)cntl - used) | (it.y & 0xFC000000u));
+                }
+                n_leaves = uni(n_leaves - __popcll(__ballot(lane < m && incl <= RT_WAVE)));
+                const int k = take;
                 bool acc = false;
                 double beta, gamma, lt = 0;
                 if (have) {
                     if (CNT) cnt.tris++;
                     V3 rc = mk(w->ray[0][rl], w->ray[1][rl], w->ray[2][rl]);
                     V3 ru = mk(w->ray[3][rl], w->ray[4][rl], w->ray[5][rl]);
-                    acc = tri_test(sc.tris + it.x, rc, ru, beta, gamma, lt) && (lt < 1E9);
+                    acc = tri_test(sc.tris + tri, rc, ru, beta, gamma, lt) && (lt < 1E9);
                 }
-                const bool more = have && count > 1u;
-                const unsigned long long bm = __ballot(more);
-                if (more) w->leaf[n_leaves + rank_in(bm)] = make_uint2(it.x + 1u, (count - 1u) | ((uint32_t)rl << 26));
-                n_leaves = uni(n_leaves + __popcll(bm));
                 if (__ballot(acc) != 0ull) {
                     /* keep (min t, then min position) per ray. LDS executes one wave's instructions in
                      * order, so every lane's atomic of one statement is done before the next statement's
@@ -302,9 +356,10 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
                         if (mine && old > cur) w->best_pos[rl] = INT32_MAX; /* this lane lowered the minimum */
                     }
                     wave_sync();
-                    if (mine) atomicMin(&w->best_pos[rl], (int32_t)it.x);
+                    if (mine) atomicMin(&w->best_pos[rl], (int32_t)tri);
                 }
                 wave_sync();
+                if (CNT) { uint64_t t = RT_STAMP(); cnt.cyc_leaf += t - st0; st0 = t; cnt.leaf_steps++; cnt.leaf_lanes += (uint64_t)k; }
             } else {
                 /* one BVH record per lane: test both child boxes (raytracer.cpp:656-665), push the hit ones */
                 const int k = n_nodes < RT_WAVE ? n_nodes : RT_WAVE;
@@ -343,6 +398,7 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
                 if (plr) w->leaf[n_leaves + c2 + rank_in(b3)] = make_uint2((uint32_t)R, (uint32_t)nR | ((uint32_t)rl << 26));
                 n_leaves = uni(n_leaves + c2 + __popcll(b3));
                 wave_sync();
+                if (CNT) { uint64_t t = RT_STAMP(); cnt.cyc_node += t - st0; st0 = t; cnt.node_steps++; cnt.node_lanes += (uint64_t)k; }
             }
         }
     }
@@ -361,6 +417,7 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
         }
     }
     wave_sync();
+    if (CNT) cnt.cyc_finish += RT_STAMP() - st0;
     return h.obj != INT32_MAX;
 }
 
@@ -462,7 +519,9 @@ __device__ __forceinline__ V3 trace_pixel(const DScene &sc, WaveLDS *w, const rt
     bool fresh = true;
     bool finished = false;
 
+    uint64_t sp0 = 0;
     while (true) {
+        if (CNT) sp0 = RT_STAMP();
         if (fresh && !finished) {
             if (k >= kend) {
                 finished = true;
@@ -499,33 +558,30 @@ __device__ __forceinline__ V3 trace_pixel(const DScene &sc, WaveLDS *w, const rt
             }
         }
         if (__ballot(!finished) == 0ull) break;
+        if (CNT) cnt.cyc_fresh += RT_STAMP() - sp0;
 
         HitRec h;
         bool inter = scene_closest_wave<CNT>(sc, w, sph, !finished, rC, ru, h, cnt);
-        if (finished) continue;
-
-        if (shadow) {
+        if (CNT) sp0 = RT_STAMP();
+        bool done = false;
+        if (finished) {
+            /* this lane only helped in the pool */
+        } else if (shadow) {
             /* raytracer.cpp:1073-1083 (or :1048-1055 for the point light): occluded iff hit before the light */
             if (!(inter && h.t < sh_limit)) Lsum = add(Lsum, cmul(T, nee));
             shadow = false;
             if (fl & RT_F_NO_INDIRECT) {
-                acc = add(acc, Lsum);
-                k++;
-                fresh = true;
-                continue;
+                done = true;
+            } else {
+                /* color += albedo * getColor(wiRay, rebond + 1, true), raytracer.cpp:1086-1088 */
+                T = cmul(T, vAlbedo);
+                rC = nextC;
+                ru = nextU;
+                rebond++;
+                lastDiffuse = true;
             }
-            /* color += albedo * getColor(wiRay, rebond + 1, true), raytracer.cpp:1086-1088 */
-            T = cmul(T, vAlbedo);
-            rC = nextC;
-            ru = nextU;
-            rebond++;
-            lastDiffuse = true;
-            continue;
-        }
-
-        /* Scene::getColor, raytracer.cpp:953-1093; the query above comes before the depth test (:960-963) */
-        bool done = false;
-        if (rebond > p.max_rebond || !inter) {
+        } else if (rebond > p.max_rebond || !inter) {
+            /* Scene::getColor, raytracer.cpp:953-1093; the query above comes before the depth test (:960-963) */
             done = true;
         } else if (h.obj == 0 && !(fl & RT_F_POINT_LIGHT)) { /* the light, :966-973 */
             if (rebond == 0 || !lastDiffuse) {
@@ -619,6 +675,7 @@ __device__ __forceinline__ V3 trace_pixel(const DScene &sc, WaveLDS *w, const rt
             k++;
             fresh = true;
         }
+        if (CNT) cnt.cyc_shade += RT_STAMP() - sp0;
     }
     return acc;
 }
@@ -633,6 +690,11 @@ __device__ __forceinline__ void flush_counters(const Cnt &c, rt_counters *out) {
         for (int off = 32; off > 0; off >>= 1) x += __shfl_xor((unsigned long long)x, off, 64);
         if ((threadIdx.x & 63) == 0 && x) atomicAdd(o + q, (unsigned long long)x);
     }
+    /* wave-level diagnostics: identical in every lane, lane 0 adds them behind the public counters */
+    uint64_t d[12] = {c.cyc_fresh, c.cyc_roots, c.cyc_node, c.cyc_leaf, c.cyc_finish, c.cyc_shade,
+                      c.node_steps, c.node_lanes, c.leaf_steps, c.leaf_lanes, c.queries, c.query_lanes};
+    if ((threadIdx.x & 63) == 0)
+        for (int q = 0; q < 12; q++) atomicAdd(o + 8 + q, (unsigned long long)d[q]);
 }
 
 } // namespace rtd

@@ -35,6 +35,21 @@ def _rel_err(a, b):
     return d.max(axis=-1)
 
 
+def test_wave_scans(gpu, rta):
+    """the DPP prefix sums the triangle step relies on"""
+    import ctypes as C
+    rng = np.random.default_rng(1)
+    for trial in range(8):
+        v = rng.integers(-1, 300, 64).astype(np.int32)
+        if trial == 0:
+            v[:] = 1
+        a = np.empty(64, np.int32); m = np.empty(64, np.int32)
+        rc = rta.lib.rt_debug_wave_scan(gpu._h, v.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        assert np.array_equal(a, np.cumsum(v)), (v, a)
+        assert np.array_equal(m, np.maximum.accumulate(v)), (v, m)
+
+
 @pytest.mark.parametrize("W", [64, 257])
 def test_primary_hits_sphere_room(gpu, rta, scenes, ob, W):
     s, cam, flags, orc = _scene_pair(ob, scenes, scenes.sphere_room, W=W)
