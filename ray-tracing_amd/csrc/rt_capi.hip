@@ -117,6 +117,147 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_intersect_kernel(DScene sc, const
     albedo[3 * q] = s.albedo.x; albedo[3 * q + 1] = s.albedo.y; albedo[3 * q + 2] = s.albedo.z;
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * wavefront form of the render loop: the per-pixel state machine of trace_pixel with its state in
+ * HBM and its loop body split into two kernels, so that the traversal kernel carries no shading
+ * registers (more waves per SIMD to hide the latency of BVH fetches) and every lane of a traversal
+ * wave has a ray (the queue of unfinished pixels is compacted every round).
+ *   round:  rt_wf_traverse  - one wave per 64 queue entries: closest hit of each pixel's current ray
+ *           rt_wf_shade     - one lane per queue entry: path_advance + path_fresh, next queue
+ * A pixel (slot) is owned by one lane at a time and its samples are added in order, so the result does
+ * not depend on how the queues are ordered.
+ * ------------------------------------------------------------------------------------------- */
+#define WF_ND 28 /* doubles per slot: rC ru T Lsum acc nee nextC nextU vAlbedo (3 each) + sh_limit */
+#define WF_NU 5  /* uint32 per slot: key lo, key hi, ctr, k, rebond | flags << 16 */
+
+struct WfBuf {
+    double *d;      /* [WF_ND][n] */
+    uint32_t *u;    /* [WF_NU][n] */
+    double *hd;     /* hit: t, beta, gamma  [3][n] */
+    int32_t *hi;    /* hit: obj, prim, mesh [3][n] */
+    int32_t *queue[2];
+    int32_t *count; /* [2] */
+    int64_t n;
+};
+
+__device__ __forceinline__ void wf_store3(double *d, int64_t n, int64_t s, int f, V3 v) {
+    d[(int64_t)f * n + s] = v.x; d[(int64_t)(f + 1) * n + s] = v.y; d[(int64_t)(f + 2) * n + s] = v.z;
+}
+__device__ __forceinline__ V3 wf_load3(const double *d, int64_t n, int64_t s, int f) {
+    return mk(d[(int64_t)f * n + s], d[(int64_t)(f + 1) * n + s], d[(int64_t)(f + 2) * n + s]);
+}
+__device__ __forceinline__ void wf_store(const WfBuf &b, int64_t s, const Path &q) {
+    wf_store3(b.d, b.n, s, 0, q.rC); wf_store3(b.d, b.n, s, 3, q.ru); wf_store3(b.d, b.n, s, 6, q.T);
+    wf_store3(b.d, b.n, s, 9, q.Lsum); wf_store3(b.d, b.n, s, 12, q.acc); wf_store3(b.d, b.n, s, 15, q.nee);
+    wf_store3(b.d, b.n, s, 18, q.nextC); wf_store3(b.d, b.n, s, 21, q.nextU); wf_store3(b.d, b.n, s, 24, q.vAlbedo);
+    b.d[27 * b.n + s] = q.sh_limit;
+    b.u[s] = (uint32_t)q.key; b.u[b.n + s] = (uint32_t)(q.key >> 32); b.u[2 * b.n + s] = q.ctr; b.u[3 * b.n + s] = (uint32_t)q.k;
+    b.u[4 * b.n + s] = (uint32_t)q.rebond | (q.lastDiffuse ? 1u << 16 : 0u) | (q.shadow ? 1u << 17 : 0u) | (q.fresh ? 1u << 18 : 0u) |
+                       (q.finished ? 1u << 19 : 0u);
+}
+__device__ __forceinline__ void wf_load(const WfBuf &b, int64_t s, Path &q) {
+    q.rC = wf_load3(b.d, b.n, s, 0); q.ru = wf_load3(b.d, b.n, s, 3); q.T = wf_load3(b.d, b.n, s, 6);
+    q.Lsum = wf_load3(b.d, b.n, s, 9); q.acc = wf_load3(b.d, b.n, s, 12); q.nee = wf_load3(b.d, b.n, s, 15);
+    q.nextC = wf_load3(b.d, b.n, s, 18); q.nextU = wf_load3(b.d, b.n, s, 21); q.vAlbedo = wf_load3(b.d, b.n, s, 24);
+    q.sh_limit = b.d[27 * b.n + s];
+    q.key = (uint64_t)b.u[s] | ((uint64_t)b.u[b.n + s] << 32); q.ctr = b.u[2 * b.n + s]; q.k = (int32_t)b.u[3 * b.n + s];
+    const uint32_t f = b.u[4 * b.n + s];
+    q.rebond = (int32_t)(f & 0xFFFFu); q.lastDiffuse = f & (1u << 16); q.shadow = f & (1u << 17); q.fresh = f & (1u << 18);
+    q.finished = f & (1u << 19);
+}
+
+/* slot -> pixel: 8x8 tiles, as lane_pixel */
+__device__ __forceinline__ bool slot_pixel(const RenderArgs &ra, int64_t slot, int &i, int &j) {
+    const int rw = ra.j1 - ra.j0;
+    const int tiles_x = (rw + 7) >> 3;
+    const int tile = (int)(slot >> 6), lane = (int)(slot & 63);
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    j = ra.j0 + tx * 8 + (lane & 7);
+    i = ra.i0 + ty * 8 + (lane >> 3);
+    return (j < ra.j1) && (i < ra.i1);
+}
+
+__global__ void __launch_bounds__(256) rt_wf_init(WfBuf b, RenderArgs ra, int k0) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= b.n) return;
+    int i, j;
+    const bool live = slot_pixel(ra, s, i, j);
+    Path q;
+    path_begin(q, k0, live);
+    wf_store(b, s, q);
+    b.queue[0][s] = (int32_t)s;
+    if (s == 0) { b.count[0] = (int32_t)b.n; b.count[1] = 0; }
+}
+
+__global__ void __launch_bounds__(RT_BLOCK) rt_wf_traverse(DScene sc, WfBuf b, int cur) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int32_t count = b.count[cur];
+    if (blockIdx.x == 0 && threadIdx.x == 0) b.count[1 - cur] = 0; /* filled by this round's shade kernel */
+    const int64_t base = (int64_t)blockIdx.x * RT_BLOCK;
+    if (base >= count) return;
+    const rt_sphere *sph;
+    WaveLDS *w = wave_setup(sc, lds_raw, &sph);
+    const int64_t idx = base + threadIdx.x;
+    const bool live = idx < count;
+    int64_t s = 0;
+    V3 C = mk(0, 0, 0), u = mk(0, 0, 1);
+    if (live) {
+        s = b.queue[cur][idx];
+        C = wf_load3(b.d, b.n, s, 0);
+        u = wf_load3(b.d, b.n, s, 3);
+    }
+    HitRec h;
+    Cnt cnt = {};
+    (void)scene_closest_wave<false>(sc, w, sph, live, C, u, h, cnt);
+    if (live) {
+        b.hd[s] = h.t; b.hd[b.n + s] = h.beta; b.hd[2 * b.n + s] = h.gamma;
+        b.hi[s] = h.obj; b.hi[b.n + s] = h.prim; b.hi[2 * b.n + s] = h.mesh;
+    }
+}
+
+__global__ void __launch_bounds__(256) rt_wf_shade(DScene sc, WfBuf b, RenderArgs ra, int cur, int kend, double *accum) {
+    const int32_t count = b.count[cur];
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool cont = false;
+    int64_t s = 0;
+    if (idx < count) {
+        s = b.queue[cur][idx];
+        Path q;
+        wf_load(b, s, q);
+        int i, j;
+        (void)slot_pixel(ra, s, i, j);
+        Cnt cnt = {};
+        if (!q.fresh && !q.finished) {
+            HitRec h;
+            h.t = b.hd[s]; h.beta = b.hd[b.n + s]; h.gamma = b.hd[2 * b.n + s];
+            h.obj = b.hi[s]; h.prim = b.hi[b.n + s]; h.mesh = b.hi[2 * b.n + s];
+            path_advance<false>(sc, sc.spheres, ra, q, h.obj != INT32_MAX, h, cnt);
+        }
+        const bool was_live = !q.finished;
+        path_fresh<false>(ra, q, i, j, kend, cnt);
+        wf_store(b, s, q);
+        if (q.finished) {
+            if (was_live) { /* this pixel's samples are done: one lane adds them (raytracer.cpp:1485) */
+                double *px = accum + ((int64_t)i * ra.p.W + j) * 3;
+                px[0] = px[0] + q.acc.x;
+                px[1] = px[1] + q.acc.y;
+                px[2] = px[2] + q.acc.z;
+            }
+        } else {
+            cont = true;
+        }
+    }
+    /* compact the pixels that go on into the next queue: one atomic per wave */
+    const unsigned long long bal = __ballot(cont);
+    if (bal) {
+        int base = 0;
+        const int lane = threadIdx.x & 63;
+        if (lane == __ffsll((long long)bal) - 1) base = atomicAdd(&b.count[1 - cur], __popcll(bal));
+        base = __shfl(base, __ffsll((long long)bal) - 1, 64);
+        if (cont) b.queue[1 - cur][base + rank_in(bal)] = (int32_t)s;
+    }
+}
+
 /* self-test of the DPP wave scans used by the triangle step */
 __global__ void __launch_bounds__(RT_BLOCK) rt_scan_test_kernel(const int *in, int *out_add, int *out_max) {
     const int v = in[threadIdx.x];
@@ -161,6 +302,11 @@ struct rt_ctx {
     int accW = 0, accH = 0;
     rt_counters *d_counters = nullptr;
     int *d_overflow = nullptr;
+    bool force_megakernel = false;
+    /* wavefront state */
+    WfBuf wf{};
+    void *wf_alloc = nullptr;
+    int64_t wf_cap = 0;
 };
 
 static std::string g_create_err;
@@ -246,6 +392,7 @@ void rt_destroy(rt_ctx *c) {
     if (c->accum) (void)hipFree(c->accum);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_overflow) (void)hipFree(c->d_overflow);
+    if (c->wf_alloc) (void)hipFree(c->wf_alloc);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -347,7 +494,7 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
         d.lightR = light->R;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream)); /* host arrays may be released after return */
-    d.node_cap = RT_WAVE * (RT_MESH_CHUNK + max_depth + 2);
+    d.node_cap = RT_NODE_SOFT + max_depth + 2;
     d.overflow = c->d_overflow;
     c->sc = d;
     c->lds_bytes = sizeof(WaveLDS) + (size_t)d.node_cap * 4 + 16 + ((s->n_spheres <= RT_LDS_SPHERES_MAX) ? (size_t)s->n_spheres * sizeof(rt_sphere) : 0);
@@ -380,6 +527,69 @@ static int check_render_args(rt_ctx *c, const rt_camera *cam, const rt_params *p
     return RT_OK;
 }
 
+/* (re)allocate the wavefront state for n slots */
+static int wf_ensure(rt_ctx *c, int64_t n) {
+    if (c->wf_alloc && c->wf_cap >= n) { c->wf.n = n; goto layout; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->wf_alloc) (void)hipFree(c->wf_alloc);
+    c->wf_alloc = nullptr;
+    {
+        const size_t bytes = (size_t)n * (WF_ND * 8 + WF_NU * 4 + 3 * 8 + 3 * 4 + 2 * 4) + 256;
+        if (hipMalloc(&c->wf_alloc, bytes) != hipSuccess) return fail(c, RT_E_NOMEM, "wavefront state allocation of %zu bytes failed", bytes);
+    }
+    c->wf_cap = n;
+    c->wf.n = n;
+layout : {
+    /* one block, carved with the CAPACITY so the layout is stable; field strides use n */
+    unsigned char *p = static_cast<unsigned char *>(c->wf_alloc);
+    const int64_t cap = c->wf_cap;
+    c->wf.d = reinterpret_cast<double *>(p); p += (size_t)cap * WF_ND * 8;
+    c->wf.hd = reinterpret_cast<double *>(p); p += (size_t)cap * 3 * 8;
+    c->wf.u = reinterpret_cast<uint32_t *>(p); p += (size_t)cap * WF_NU * 4;
+    c->wf.hi = reinterpret_cast<int32_t *>(p); p += (size_t)cap * 3 * 4;
+    c->wf.queue[0] = reinterpret_cast<int32_t *>(p); p += (size_t)cap * 4;
+    c->wf.queue[1] = reinterpret_cast<int32_t *>(p); p += (size_t)cap * 4;
+    c->wf.count = reinterpret_cast<int32_t *>(p);
+}
+    return RT_OK;
+}
+
+/* rounds between two reads of the queue length (the host sizes the grids from it) */
+static const int kRoundsPerCheck = 16;
+
+static int render_wavefront(rt_ctx *c, const RenderArgs &ra, const rt_params *p, double *accum, int64_t tiles) {
+    const int64_t n = tiles * 64;
+    int rc = wf_ensure(c, n);
+    if (rc) return rc;
+    const WfBuf b = c->wf;
+    const int kend = p->spp_offset + p->spp;
+    hipLaunchKernelGGL(rt_wf_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, b, ra, p->spp_offset);
+    HIPCHK(c, hipGetLastError());
+    c->last_launches++;
+    /* round "-1": generate the first camera rays and the first queue */
+    hipLaunchKernelGGL(rt_wf_shade, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->sc, b, ra, 0, kend, accum);
+    HIPCHK(c, hipGetLastError());
+    c->last_launches++;
+    int cur = 1;
+    int64_t known = n; /* upper bound of the queue length: it never grows */
+    for (int64_t round = 0;; round++) {
+        hipLaunchKernelGGL(rt_wf_traverse, dim3((unsigned)((known + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, b, cur);
+        HIPCHK(c, hipGetLastError());
+        hipLaunchKernelGGL(rt_wf_shade, dim3((unsigned)((known + 255) / 256)), dim3(256), 0, c->stream, c->sc, b, ra, cur, kend, accum);
+        HIPCHK(c, hipGetLastError());
+        c->last_launches += 2;
+        cur = 1 - cur;
+        if (round % kRoundsPerCheck == kRoundsPerCheck - 1) {
+            int32_t cnt = 0;
+            HIPCHK(c, hipMemcpyAsync(&cnt, b.count + cur, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            known = cnt;
+            if (known == 0) break;
+        }
+    }
+    return RT_OK;
+}
+
 /* samples per kernel launch: long renders are cut into several launches of bounded duration */
 static const int kSppPerLaunch = 64;
 
@@ -400,14 +610,20 @@ int rt_render(rt_ctx *c, const rt_camera *cam, const rt_params *p, double *accum
     c->last_launches = 0;
     c->timed = false;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    for (int k = 0; k < p->spp; k += kSppPerLaunch) {
-        const int nk = (p->spp - k < kSppPerLaunch) ? (p->spp - k) : kSppPerLaunch;
-        if (p->flags & RT_F_COUNTERS)
-            hipLaunchKernelGGL(rt_render_kernel<true>, dim3(grid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, accum, c->d_counters);
-        else
-            hipLaunchKernelGGL(rt_render_kernel<false>, dim3(grid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, accum, c->d_counters);
-        HIPCHK(c, hipGetLastError());
-        c->last_launches++;
+    if ((p->flags & RT_F_COUNTERS) || c->force_megakernel) {
+        /* single-kernel form: the counted variant, and an A/B switch for measurements */
+        for (int k = 0; k < p->spp; k += kSppPerLaunch) {
+            const int nk = (p->spp - k < kSppPerLaunch) ? (p->spp - k) : kSppPerLaunch;
+            if (p->flags & RT_F_COUNTERS)
+                hipLaunchKernelGGL(rt_render_kernel<true>, dim3(grid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, accum, c->d_counters);
+            else
+                hipLaunchKernelGGL(rt_render_kernel<false>, dim3(grid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, accum, c->d_counters);
+            HIPCHK(c, hipGetLastError());
+            c->last_launches++;
+        }
+    } else if (p->spp > 0) {
+        rc = render_wavefront(c, ra, p, accum, tiles);
+        if (rc) return rc;
     }
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->timed = true;
@@ -550,6 +766,13 @@ int rt_debug_stats(rt_ctx *c, uint64_t *out12) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(out12, reinterpret_cast<uint64_t *>(c->d_counters) + 8, 12 * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+/* not part of the public header: A/B switch between the wavefront and the single-kernel render (tools/ only) */
+int rt_debug_force_megakernel(rt_ctx *c, int on) {
+    if (!c) return RT_E_INVALID;
+    c->force_megakernel = on != 0;
     return RT_OK;
 }
 

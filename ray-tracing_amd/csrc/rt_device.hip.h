@@ -33,8 +33,9 @@ namespace rtd {
 
 #define RT_WAVE 64
 #define RT_LDS_SPHERES_MAX 64     /* sphere lists up to this size are staged in LDS */
-#define RT_MESH_CHUNK 16          /* meshes whose roots enter the pool together */
-#define RT_LEAF_CAP 512           /* leaf-item stack entries */
+#define RT_MESH_CHUNK 8           /* meshes whose roots enter the pool together */
+#define RT_NODE_SOFT 1024         /* node-item stack height up to which 64 items are popped per step */
+#define RT_LEAF_CAP 256           /* leaf-item stack entries */
 #define RT_LEAF_TRIGGER 24        /* pending leaf items that make the next pool step a triangle step */
 #define RT_NODE_BITS 26           /* node index bits in a node item (the ray lane takes the top 6) */
 #define RT_MAX_DEPTH 60
@@ -49,7 +50,7 @@ struct DScene {
     const uint8_t *texels;
     const double *lut;
     int32_t n_spheres, n_meshes;
-    int32_t node_cap; /* node-item stack entries: 64 * (RT_MESH_CHUNK + max_depth + 2) */
+    int32_t node_cap; /* node-item stack entries: RT_NODE_SOFT + max_depth + 2 */
     int32_t pad;
     int *overflow;    /* set to 1 if a node push would have passed node_cap */
     double I;
@@ -112,12 +113,16 @@ struct Cnt {
 #define RT_STAMP() ((uint64_t)__builtin_amdgcn_s_memtime())
 
 /* BoudingBox::intersect, raytracer.cpp:163-186 (six true divisions, no bound on t) */
-__device__ __noinline__ bool box_hit_exact(const double *b, V3 C, V3 u) {
-    double t1x = (b[0] - C.x) / u.x, t2x = (b[3] - C.x) / u.x;
+struct Box6 {
+    double lx, ly, lz, hx, hy, hz;
+};
+__device__ __forceinline__ Box6 ldbox(const double *b) { return Box6{b[0], b[1], b[2], b[3], b[4], b[5]}; }
+__device__ __noinline__ bool box_hit_exact(Box6 b, V3 C, V3 u) {
+    double t1x = (b.lx - C.x) / u.x, t2x = (b.hx - C.x) / u.x;
     double txMin = smin(t1x, t2x), txMax = smax(t1x, t2x);
-    double t1y = (b[1] - C.y) / u.y, t2y = (b[4] - C.y) / u.y;
+    double t1y = (b.ly - C.y) / u.y, t2y = (b.hy - C.y) / u.y;
     double tyMin = smin(t1y, t2y), tyMax = smax(t1y, t2y);
-    double t1z = (b[2] - C.z) / u.z, t2z = (b[5] - C.z) / u.z;
+    double t1z = (b.lz - C.z) / u.z, t2z = (b.hz - C.z) / u.z;
     double tzMin = smin(t1z, t2z), tzMax = smax(t1z, t2z);
     double tMax = smin(txMax, smin(tyMax, tzMax));
     double tMin = smax(txMin, smax(tyMin, tzMin));
@@ -132,15 +137,14 @@ __device__ __noinline__ bool box_hit_exact(const double *b, V3 C, V3 u) {
  * "tMax < 0" and "tMax > tMin" come out as with true divisions. Everything else - a zero-thickness
  * box (tMax == tMin), a grazing ray, infinities or NaNs from a zero direction component - goes
  * through the true divisions. */
-__device__ __forceinline__ bool box_hit(const double *b, V3 C, V3 u, V3 iu) {
-    double t1x = (b[0] - C.x) * iu.x, t2x = (b[3] - C.x) * iu.x;
-    double txMin = smin(t1x, t2x), txMax = smax(t1x, t2x);
-    double t1y = (b[1] - C.y) * iu.y, t2y = (b[4] - C.y) * iu.y;
-    double tyMin = smin(t1y, t2y), tyMax = smax(t1y, t2y);
-    double t1z = (b[2] - C.z) * iu.z, t2z = (b[5] - C.z) * iu.z;
-    double tzMin = smin(t1z, t2z), tzMax = smax(t1z, t2z);
-    double tMax = smin(txMax, smin(tyMax, tzMax));
-    double tMin = smax(txMin, smax(tyMin, tzMin));
+__device__ __forceinline__ bool box_hit(Box6 b, V3 C, V3 u, V3 iu) {
+    double t1x = (b.lx - C.x) * iu.x, t2x = (b.hx - C.x) * iu.x;
+    double t1y = (b.ly - C.y) * iu.y, t2y = (b.hy - C.y) * iu.y;
+    double t1z = (b.lz - C.z) * iu.z, t2z = (b.hz - C.z) * iu.z;
+    /* fmin/fmax (one instruction each) agree with std::min/std::max on finite values; any infinity or
+     * NaN sends the box to the exact path below, so their different NaN rules never matter */
+    double tMax = fmin(fmax(t1x, t2x), fmin(fmax(t1y, t2y), fmax(t1z, t2z)));
+    double tMin = fmax(fmin(t1x, t2x), fmax(fmin(t1y, t2y), fmin(t1z, t2z)));
     double gap = fabs(tMax - tMin), mag = fabs(tMax) + fabs(tMin);
     /* (x - x) is 0 for finite x and NaN otherwise: one test for "all six are finite" */
     double fin = (t1x - t1x) + (t2x - t2x) + (t1y - t1y) + (t2y - t2y) + (t1z - t1z) + (t2z - t2z);
@@ -281,7 +285,7 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
             bool pass = false;
             if (active) {
                 if (CNT) cnt.box_tests++;
-                pass = box_hit(m.root_box, C, u, iu);
+                pass = box_hit(ldbox(m.root_box), C, u, iu);
                 if (CNT && pass) cnt.mesh_calls++;
             }
             const unsigned long long bal = __ballot(pass);
@@ -362,7 +366,12 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
                 if (CNT) { uint64_t t = RT_STAMP(); cnt.cyc_leaf += t - st0; st0 = t; cnt.leaf_steps++; cnt.leaf_lanes += (uint64_t)k; }
             } else {
                 /* one BVH record per lane: test both child boxes (raytracer.cpp:656-665), push the hit ones */
-                const int k = n_nodes < RT_WAVE ? n_nodes : RT_WAVE;
+                /* Up to 64 records per step while the stack is below RT_NODE_SOFT (a step can add one
+                 * entry per record popped); above it one record per step, a plain depth-first descent
+                 * that needs at most max_depth + 1 entries more. */
+                int k = n_nodes < RT_WAVE ? n_nodes : RT_WAVE;
+                const int room = RT_NODE_SOFT - n_nodes;
+                if (k > room) k = room > 1 ? room : 1;
                 const bool have = lane < k;
                 uint32_t it = 0;
                 if (have) it = w->node[n_nodes - 1 - lane];
@@ -372,14 +381,16 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
                 bool pnl = false, pnr = false, pll = false, plr = false;
                 int32_t L = 0, R = 0, nL = 0, nR = 0;
                 if (have) {
+                    /* the whole 128-byte record in one batch of loads, before either box is tested */
                     const rt_bvh_node *nd = sc.nodes + (it & ((1u << RT_NODE_BITS) - 1u));
+                    const Box6 bl = ldbox(nd->boxL), br = ldbox(nd->boxR);
                     if (CNT) { cnt.nodes++; cnt.box_tests += 2; }
                     V3 rc = mk(w->ray[0][rl], w->ray[1][rl], w->ray[2][rl]);
                     V3 ru = mk(w->ray[3][rl], w->ray[4][rl], w->ray[5][rl]);
                     V3 ri = mk(w->ray[6][rl], w->ray[7][rl], w->ray[8][rl]);
                     L = nd->L; R = nd->R; nL = nd->nL; nR = nd->nR;
-                    const bool hl = box_hit(nd->boxL, rc, ru, ri);
-                    const bool hr = box_hit(nd->boxR, rc, ru, ri);
+                    const bool hl = box_hit(bl, rc, ru, ri);
+                    const bool hr = box_hit(br, rc, ru, ri);
                     pnl = hl && nL == 0; pll = hl && nL > 0;
                     pnr = hr && nR == 0; plr = hr && nR > 0;
                 }
@@ -485,199 +496,215 @@ struct RenderArgs {
     int32_t j0, i0, j1, i1;
 };
 
-/* Sum of the radiance of samples k0 .. k0+nk-1 of pixel (i, j), added in that order (the k loop of
- * raytracer.cpp:1464-1486). Called by all 64 lanes of the wave; lanes with live == false only help
- * in the pool. */
+/* State of one pixel's sample loop between two closest-hit queries: the ray to trace next and what
+ * the recursion of Scene::getColor would hold on its stack. */
+struct Path {
+    V3 rC, ru;      /* ray being traced */
+    V3 T, Lsum;     /* throughput and radiance of the current path */
+    V3 acc;         /* sum over the finished samples of this pixel (raytracer.cpp:1463, :1485) */
+    V3 nee, nextC, nextU, vAlbedo; /* pending diffuse vertex while its shadow ray is traced */
+    double sh_limit;
+    uint64_t key;   /* random stream of the current sample */
+    uint32_t ctr;   /* draws used so far */
+    int32_t k;      /* current sample index */
+    int32_t rebond;
+    bool lastDiffuse, shadow, fresh, finished;
+};
+
+__device__ __forceinline__ void path_begin(Path &q, int k0, bool live) {
+    q.rC = mk(0, 0, 0); q.ru = mk(0, 0, 1);
+    q.T = mk(1, 1, 1); q.Lsum = mk(0, 0, 0); q.acc = mk(0, 0, 0);
+    q.nee = q.nextC = q.nextU = q.vAlbedo = mk(0, 0, 0);
+    q.sh_limit = 0; q.key = 0; q.ctr = 0; q.k = k0; q.rebond = 0;
+    q.lastDiffuse = false; q.shadow = false; q.fresh = true; q.finished = !live;
+}
+
+/* Start the next sample of pixel (i, j) if the previous one has ended: one iteration of the k loop
+ * up to the getColor call, raytracer.cpp:1464-1483. */
+template <bool CNT>
+__device__ __forceinline__ void path_fresh(const RenderArgs &ra, Path &q, int i, int j, int kend, Cnt &cnt) {
+    if (!q.fresh || q.finished) return;
+    if (q.k >= kend) { q.finished = true; return; }
+    const rt_params &p = ra.p;
+    const rt_camera &cam = ra.cam;
+    const V3 camC = ld3(cam.C), right = ld3(cam.right), up = ld3(cam.up), view = ld3(cam.view);
+    if (CNT) cnt.paths++;
+    q.key = rng_key(ra.seed_mixed, (uint32_t)(i * p.W + j), (uint32_t)q.k);
+    q.ctr = 0;
+    if (p.flags & RT_F_NO_JITTER) { /* Ray r(C, u), raytracer.cpp:1482 */
+        V3 d = mk(j - p.W / 2 + 0.5, i - p.H / 2 + 0.5, cam.zdist);
+        d = unit(d);
+        q.ru = add(add(smul(d.x, right), smul(d.y, up)), smul(d.z, view));
+        q.rC = camC;
+    } else { /* raytracer.cpp:1467-1483 */
+        double u1 = rng_uniform(q.key, 0), u2 = rng_uniform(q.key, 1);
+        double x1 = cam.aa_sigma * cos(2 * RT_PI * u1) * sqrt(-2 * log(u2)),
+               x2 = cam.aa_sigma * sin(2 * RT_PI * u1) * sqrt(-2 * log(u2));
+        double u3 = rng_uniform(q.key, 2), u4 = rng_uniform(q.key, 3);
+        double x3 = cam.dof_sigma * cos(2 * RT_PI * u3) * sqrt(-2 * log(u4)),
+               x4 = cam.dof_sigma * sin(2 * RT_PI * u3) * sqrt(-2 * log(u4));
+        q.ctr = 4;
+        V3 d = mk(j - p.W / 2 + x2 + 0.5, i - p.H / 2 + x1 + 0.5, cam.zdist);
+        d = unit(d);
+        d = add(add(smul(d.x, right), smul(d.y, up)), smul(d.z, view));
+        V3 target = add(camC, smul(cam.focus, d));
+        q.rC = add(camC, mk(x3, x4, 0));
+        q.ru = unit(sub(target, q.rC));
+    }
+    q.Lsum = mk(0, 0, 0);
+    q.T = mk(1, 1, 1);
+    q.rebond = 0;
+    q.lastDiffuse = false;
+    q.shadow = false;
+    q.fresh = false;
+}
+
+/* One step of Scene::getColor (raytracer.cpp:953-1093) given the closest hit of the ray that was
+ * traced: either the pending shadow ray of a diffuse vertex or a path segment. Leaves the next ray
+ * in (rC, ru) or ends the sample (fresh = true). */
+template <bool CNT>
+__device__ __forceinline__ void path_advance(const DScene &sc, const rt_sphere *sph, const RenderArgs &ra, Path &q, bool inter,
+                                             const HitRec &h, Cnt &cnt) {
+    const rt_params &p = ra.p;
+    const uint32_t fl = p.flags;
+    const double epsilon = p.epsilon;
+    bool done = false;
+    if (q.shadow) {
+        /* raytracer.cpp:1073-1083 (or :1048-1055 for the point light): occluded iff hit before the light */
+        if (!(inter && h.t < q.sh_limit)) q.Lsum = add(q.Lsum, cmul(q.T, q.nee));
+        q.shadow = false;
+        if (fl & RT_F_NO_INDIRECT) {
+            done = true;
+        } else {
+            /* color += albedo * getColor(wiRay, rebond + 1, true), raytracer.cpp:1086-1088 */
+            q.T = cmul(q.T, q.vAlbedo);
+            q.rC = q.nextC;
+            q.ru = q.nextU;
+            q.rebond++;
+            q.lastDiffuse = true;
+        }
+    } else if (q.rebond > p.max_rebond || !inter) {
+        /* the query comes before the depth test (:960-963) */
+        done = true;
+    } else if (h.obj == 0 && !(fl & RT_F_POINT_LIGHT)) { /* the light, :966-973 */
+        if (q.rebond == 0 || !q.lastDiffuse) {
+            double e = sc.I / (4 * RT_PI * RT_PI * sqr(sc.lightR));
+            q.Lsum = add(q.Lsum, cmul(q.T, mk(e, e, e)));
+        }
+        done = true;
+    } else {
+        Surf s;
+        hit_surface(sc, sph, q.rC, q.ru, h, s);
+        const V3 P = s.P, N = s.N, ru = q.ru;
+        if (s.flags & RT_MAT_MIRROR) { /* :974-979 */
+            if (CNT) cnt.specular++;
+            V3 rd = sub(ru, smul(2 * dot(ru, N), N));
+            q.rC = add(P, smul(epsilon, N));
+            q.ru = rd;
+            q.rebond++;
+            q.lastDiffuse = false;
+        } else if (s.flags & RT_MAT_TRANSPARENT) { /* :982-1021 */
+            if (CNT) cnt.specular++;
+            double n1 = 1, n2 = p.ior;
+            V3 N2 = N;
+            if (dot(ru, N) > 0) {
+                double tmp = n1; n1 = n2; n2 = tmp;
+                N2 = neg(N);
+            }
+            double rad = 1 - sqr(n1 / n2) * (1 - sqr(dot(ru, N2)));
+            bool reflect;
+            if (rad < 0) {
+                reflect = true;
+            } else if (fl & RT_F_NO_FRESNEL) {
+                reflect = false;
+            } else {
+                double k0 = sqr(n1 - n2) / sqr(n1 + n2);
+                double R = k0 + (1 - k0) * sqr(sqr(1 - fabs(dot(N2, ru)))) * (1 - fabs(dot(N2, ru)));
+                double random = (double)((int)(rng_draw(q.key, q.ctr) >> 33) % 100); /* rand() % 100, :1006 */
+                q.ctr++;
+                reflect = (random <= 100 * R);
+            }
+            if (reflect) { /* offset along N, not N2: :997, :1011 */
+                V3 rd = sub(ru, smul(2 * dot(ru, N), N));
+                q.rC = add(P, smul(epsilon, N));
+                q.ru = rd;
+            } else {
+                V3 tT = smul(n1 / n2, sub(ru, smul(dot(ru, N2), N2)));
+                V3 tN = smul(-sqrt(rad), N2);
+                q.rC = sub(P, smul(epsilon, N2));
+                q.ru = add(tT, tN);
+            }
+            q.rebond++;
+            q.lastDiffuse = false;
+        } else { /* diffuse: direct light now, indirect ray after the shadow query */
+            if (CNT) cnt.diffuse++;
+            const V3 Lpos = ld3(sc.L);
+            V3 shC = add(P, smul(0.00001, N)), shU;
+            if (fl & RT_F_POINT_LIGHT) { /* :1040-1055 */
+                V3 PL = sub(Lpos, P);
+                double d = sqrt(norm2(PL));
+                shU = divs(PL, d);
+                q.nee = muls(smul(sc.I / (4 * RT_PI * d * d), divs(s.albedo, RT_PI)), smax(0., dot(N, divs(PL, d))));
+                q.sh_limit = d;
+            } else { /* :1059-1083 */
+                const V3 lightO = ld3(sc.lightO);
+                const double lightR = sc.lightR;
+                V3 PL = unit(sub(Lpos, P));
+                double u1 = rng_uniform(q.key, q.ctr), u2 = rng_uniform(q.key, q.ctr + 1);
+                q.ctr += 2;
+                V3 wv = random_cos(u1, u2, neg(PL));
+                V3 xprime = add(muls(wv, lightR), lightO);
+                V3 Px = sub(xprime, P);
+                double d = sqrt(norm2(Px));
+                Px = divs(Px, d);
+                shU = Px;
+                double R2 = sqr(lightR);
+                double proba = smax(1E-8, dot(neg(PL), wv)) / (RT_PI * R2);
+                double J = smax(0., dot(wv, neg(Px))) / (d * d);
+                q.nee = divs(muls(muls(smul(sc.I / (4 * RT_PI * RT_PI * R2), divs(s.albedo, RT_PI)), smax(0., dot(N, Px))), J), proba);
+                q.sh_limit = d - p.shadow_bias;
+            }
+            if (!(fl & RT_F_NO_INDIRECT)) { /* :1086-1087; its two draws follow the light's two */
+                double u1 = rng_uniform(q.key, q.ctr), u2 = rng_uniform(q.key, q.ctr + 1);
+                q.ctr += 2;
+                q.nextU = random_cos(u1, u2, N);
+                q.nextC = add(P, smul(epsilon, N));
+                q.vAlbedo = s.albedo;
+            }
+            q.rC = shC;
+            q.ru = shU;
+            q.shadow = true;
+        }
+    }
+    if (done) {
+        q.acc = add(q.acc, q.Lsum);
+        q.k++;
+        q.fresh = true;
+    }
+}
+
+/* Single-kernel form: sum of the radiance of samples k0 .. k0+nk-1 of pixel (i, j), added in that
+ * order (the k loop of raytracer.cpp:1464-1486). Called by all 64 lanes of the wave; lanes with
+ * live == false only help in the pool. */
 template <bool CNT>
 __device__ __forceinline__ V3 trace_pixel(const DScene &sc, WaveLDS *w, const rt_sphere *sph, const RenderArgs &ra, bool live, int i,
                                           int j, int k0, int nk, Cnt &cnt) {
-    const rt_params &p = ra.p;
-    const rt_camera &cam = ra.cam;
-    const uint32_t fl = p.flags;
-    const double epsilon = p.epsilon;
-    const V3 camC = ld3(cam.C), right = ld3(cam.right), up = ld3(cam.up), view = ld3(cam.view);
-    const V3 Lpos = ld3(sc.L);
-    const V3 lightO = ld3(sc.lightO);
-    const double lightR = sc.lightR;
-    const uint32_t pixel = (uint32_t)(i * p.W + j);
-
-    V3 acc = mk(0, 0, 0);
-    int k = k0;
-    const int kend = live ? k0 + nk : k0;
-
-    /* per-path state */
-    uint64_t key = 0;
-    uint32_t ctr = 0;
-    V3 rC = mk(0, 0, 0), ru = mk(0, 0, 1); /* ray being traced */
-    V3 Lsum = mk(0, 0, 0), T = mk(1, 1, 1);
-    int rebond = 0;
-    bool lastDiffuse = false;
-    bool shadow = false; /* the ray being traced is the shadow ray of a diffuse vertex */
-    /* pending state of the diffuse vertex while its shadow ray is traced */
-    V3 nee = mk(0, 0, 0), nextC = mk(0, 0, 0), nextU = mk(0, 0, 0), vAlbedo = mk(0, 0, 0);
-    double sh_limit = 0;
-    bool fresh = true;
-    bool finished = false;
-
+    Path q;
+    path_begin(q, k0, live);
+    const int kend = k0 + nk;
     uint64_t sp0 = 0;
     while (true) {
         if (CNT) sp0 = RT_STAMP();
-        if (fresh && !finished) {
-            if (k >= kend) {
-                finished = true;
-            } else {
-                if (CNT) cnt.paths++;
-                key = rng_key(ra.seed_mixed, pixel, (uint32_t)k);
-                ctr = 0;
-                if (fl & RT_F_NO_JITTER) { /* Ray r(C, u), raytracer.cpp:1482 */
-                    V3 d = mk(j - p.W / 2 + 0.5, i - p.H / 2 + 0.5, cam.zdist);
-                    d = unit(d);
-                    ru = add(add(smul(d.x, right), smul(d.y, up)), smul(d.z, view));
-                    rC = camC;
-                } else { /* raytracer.cpp:1467-1483 */
-                    double u1 = rng_uniform(key, 0), u2 = rng_uniform(key, 1);
-                    double x1 = cam.aa_sigma * cos(2 * RT_PI * u1) * sqrt(-2 * log(u2)),
-                           x2 = cam.aa_sigma * sin(2 * RT_PI * u1) * sqrt(-2 * log(u2));
-                    double u3 = rng_uniform(key, 2), u4 = rng_uniform(key, 3);
-                    double x3 = cam.dof_sigma * cos(2 * RT_PI * u3) * sqrt(-2 * log(u4)),
-                           x4 = cam.dof_sigma * sin(2 * RT_PI * u3) * sqrt(-2 * log(u4));
-                    ctr = 4;
-                    V3 d = mk(j - p.W / 2 + x2 + 0.5, i - p.H / 2 + x1 + 0.5, cam.zdist);
-                    d = unit(d);
-                    d = add(add(smul(d.x, right), smul(d.y, up)), smul(d.z, view));
-                    V3 target = add(camC, smul(cam.focus, d));
-                    rC = add(camC, mk(x3, x4, 0));
-                    ru = unit(sub(target, rC));
-                }
-                Lsum = mk(0, 0, 0);
-                T = mk(1, 1, 1);
-                rebond = 0;
-                lastDiffuse = false;
-                shadow = false;
-                fresh = false;
-            }
-        }
-        if (__ballot(!finished) == 0ull) break;
+        path_fresh<CNT>(ra, q, i, j, kend, cnt);
+        if (__ballot(!q.finished) == 0ull) break;
         if (CNT) cnt.cyc_fresh += RT_STAMP() - sp0;
-
         HitRec h;
-        bool inter = scene_closest_wave<CNT>(sc, w, sph, !finished, rC, ru, h, cnt);
+        bool inter = scene_closest_wave<CNT>(sc, w, sph, !q.finished, q.rC, q.ru, h, cnt);
         if (CNT) sp0 = RT_STAMP();
-        bool done = false;
-        if (finished) {
-            /* this lane only helped in the pool */
-        } else if (shadow) {
-            /* raytracer.cpp:1073-1083 (or :1048-1055 for the point light): occluded iff hit before the light */
-            if (!(inter && h.t < sh_limit)) Lsum = add(Lsum, cmul(T, nee));
-            shadow = false;
-            if (fl & RT_F_NO_INDIRECT) {
-                done = true;
-            } else {
-                /* color += albedo * getColor(wiRay, rebond + 1, true), raytracer.cpp:1086-1088 */
-                T = cmul(T, vAlbedo);
-                rC = nextC;
-                ru = nextU;
-                rebond++;
-                lastDiffuse = true;
-            }
-        } else if (rebond > p.max_rebond || !inter) {
-            /* Scene::getColor, raytracer.cpp:953-1093; the query above comes before the depth test (:960-963) */
-            done = true;
-        } else if (h.obj == 0 && !(fl & RT_F_POINT_LIGHT)) { /* the light, :966-973 */
-            if (rebond == 0 || !lastDiffuse) {
-                double e = sc.I / (4 * RT_PI * RT_PI * sqr(lightR));
-                Lsum = add(Lsum, cmul(T, mk(e, e, e)));
-            }
-            done = true;
-        } else {
-            Surf s;
-            hit_surface(sc, sph, rC, ru, h, s);
-            const V3 P = s.P, N = s.N;
-            if (s.flags & RT_MAT_MIRROR) { /* :974-979 */
-                if (CNT) cnt.specular++;
-                V3 rd = sub(ru, smul(2 * dot(ru, N), N));
-                rC = add(P, smul(epsilon, N));
-                ru = rd;
-                rebond++;
-                lastDiffuse = false;
-            } else if (s.flags & RT_MAT_TRANSPARENT) { /* :982-1021 */
-                if (CNT) cnt.specular++;
-                double n1 = 1, n2 = p.ior;
-                V3 N2 = N;
-                if (dot(ru, N) > 0) {
-                    double tmp = n1; n1 = n2; n2 = tmp;
-                    N2 = neg(N);
-                }
-                double rad = 1 - sqr(n1 / n2) * (1 - sqr(dot(ru, N2)));
-                bool reflect;
-                if (rad < 0) {
-                    reflect = true;
-                } else if (fl & RT_F_NO_FRESNEL) {
-                    reflect = false;
-                } else {
-                    double k0 = sqr(n1 - n2) / sqr(n1 + n2);
-                    double R = k0 + (1 - k0) * sqr(sqr(1 - fabs(dot(N2, ru)))) * (1 - fabs(dot(N2, ru)));
-                    double random = (double)((int)(rng_draw(key, ctr) >> 33) % 100); /* rand() % 100, :1006 */
-                    ctr++;
-                    reflect = (random <= 100 * R);
-                }
-                if (reflect) { /* offset along N, not N2: :997, :1011 */
-                    V3 rd = sub(ru, smul(2 * dot(ru, N), N));
-                    rC = add(P, smul(epsilon, N));
-                    ru = rd;
-                } else {
-                    V3 tT = smul(n1 / n2, sub(ru, smul(dot(ru, N2), N2)));
-                    V3 tN = smul(-sqrt(rad), N2);
-                    rC = sub(P, smul(epsilon, N2));
-                    ru = add(tT, tN);
-                }
-                rebond++;
-                lastDiffuse = false;
-            } else { /* diffuse: direct light now, indirect ray after the shadow query */
-                if (CNT) cnt.diffuse++;
-                V3 shC = add(P, smul(0.00001, N)), shU;
-                if (fl & RT_F_POINT_LIGHT) { /* :1040-1055 */
-                    V3 PL = sub(Lpos, P);
-                    double d = sqrt(norm2(PL));
-                    shU = divs(PL, d);
-                    nee = muls(smul(sc.I / (4 * RT_PI * d * d), divs(s.albedo, RT_PI)), smax(0., dot(N, divs(PL, d))));
-                    sh_limit = d;
-                } else { /* :1059-1083 */
-                    V3 PL = unit(sub(Lpos, P));
-                    double u1 = rng_uniform(key, ctr), u2 = rng_uniform(key, ctr + 1);
-                    ctr += 2;
-                    V3 wv = random_cos(u1, u2, neg(PL));
-                    V3 xprime = add(muls(wv, lightR), lightO);
-                    V3 Px = sub(xprime, P);
-                    double d = sqrt(norm2(Px));
-                    Px = divs(Px, d);
-                    shU = Px;
-                    double R2 = sqr(lightR);
-                    double proba = smax(1E-8, dot(neg(PL), wv)) / (RT_PI * R2);
-                    double J = smax(0., dot(wv, neg(Px))) / (d * d);
-                    nee = divs(muls(muls(smul(sc.I / (4 * RT_PI * RT_PI * R2), divs(s.albedo, RT_PI)), smax(0., dot(N, Px))), J), proba);
-                    sh_limit = d - p.shadow_bias;
-                }
-                if (!(fl & RT_F_NO_INDIRECT)) { /* :1086-1087; its two draws follow the light's two */
-                    double u1 = rng_uniform(key, ctr), u2 = rng_uniform(key, ctr + 1);
-                    ctr += 2;
-                    nextU = random_cos(u1, u2, N);
-                    nextC = add(P, smul(epsilon, N));
-                    vAlbedo = s.albedo;
-                }
-                rC = shC;
-                ru = shU;
-                shadow = true;
-            }
-        }
-        if (done) {
-            acc = add(acc, Lsum);
-            k++;
-            fresh = true;
-        }
+        if (!q.finished) path_advance<CNT>(sc, sph, ra, q, inter, h, cnt);
         if (CNT) cnt.cyc_shade += RT_STAMP() - sp0;
     }
-    return acc;
+    return q.acc;
 }
 
 /* wave-reduce a counter set and add it to global memory with one atomic per field per wave */
