@@ -92,8 +92,8 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_sample_kernel(DScene sc, RenderAr
 }
 
 /* Scene::intersect probe */
-__global__ void __launch_bounds__(RT_BLOCK) rt_intersect_kernel(DScene sc, const double *rays, int64_t n, int32_t *obj_id, int32_t *tri_id,
-                                                                double *t, double *PN, double *albedo) {
+__global__ void __launch_bounds__(RT_BLOCK) rt_intersect_kernel(DScene sc, const double *rays, int64_t n, int prune, int32_t *obj_id,
+                                                                int32_t *tri_id, double *t, double *PN, double *albedo) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const rt_sphere *sph;
     WaveLDS *w = wave_setup(sc, lds_raw, &sph);
@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_intersect_kernel(DScene sc, const
     if (live) { C = ld3(rays + 6 * q); u = ld3(rays + 6 * q + 3); }
     HitRec h;
     Cnt cnt = {};
-    bool ok = scene_closest_wave<false>(sc, w, sph, live, C, u, h, cnt);
+    bool ok = scene_closest_wave<false>(sc, w, sph, live, C, u, 1E10, false, prune != 0, h, cnt);
     if (!live) return;
     obj_id[q] = ok ? h.obj : -1;
     tri_id[q] = (ok && h.mesh >= 0) ? sc.tris[h.prim].orig_id : -1;
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(256) rt_wf_init(WfBuf b, RenderArgs ra, int k0
     if (s == 0) { b.count[0] = (int32_t)b.n; b.count[1] = 0; }
 }
 
-__global__ void __launch_bounds__(RT_BLOCK) rt_wf_traverse(DScene sc, WfBuf b, int cur) {
+__global__ void __launch_bounds__(RT_BLOCK) rt_wf_traverse(DScene sc, WfBuf b, int cur, int prune) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int32_t count = b.count[cur];
     if (blockIdx.x == 0 && threadIdx.x == 0) b.count[1 - cur] = 0; /* filled by this round's shade kernel */
@@ -201,14 +201,18 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_wf_traverse(DScene sc, WfBuf b, i
     const bool live = idx < count;
     int64_t s = 0;
     V3 C = mk(0, 0, 0), u = mk(0, 0, 1);
+    double tmax = 1E10;
+    bool shadow = false;
     if (live) {
         s = b.queue[cur][idx];
         C = wf_load3(b.d, b.n, s, 0);
         u = wf_load3(b.d, b.n, s, 3);
+        shadow = b.u[4 * b.n + s] & (1u << 17);
+        if (shadow) tmax = b.d[27 * b.n + s];
     }
     HitRec h;
     Cnt cnt = {};
-    (void)scene_closest_wave<false>(sc, w, sph, live, C, u, h, cnt);
+    (void)scene_closest_wave<false>(sc, w, sph, live, C, u, tmax, shadow, prune != 0, h, cnt);
     if (live) {
         b.hd[s] = h.t; b.hd[b.n + s] = h.beta; b.hd[2 * b.n + s] = h.gamma;
         b.hi[s] = h.obj; b.hi[b.n + s] = h.prim; b.hi[2 * b.n + s] = h.mesh;
@@ -303,6 +307,7 @@ struct rt_ctx {
     rt_counters *d_counters = nullptr;
     int *d_overflow = nullptr;
     bool force_megakernel = false;
+    bool probe_prune = true;
     /* wavefront state */
     WfBuf wf{};
     void *wf_alloc = nullptr;
@@ -497,7 +502,7 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
     d.node_cap = RT_NODE_SOFT + max_depth + 2;
     d.overflow = c->d_overflow;
     c->sc = d;
-    c->lds_bytes = sizeof(WaveLDS) + (size_t)d.node_cap * 4 + 16 + ((s->n_spheres <= RT_LDS_SPHERES_MAX) ? (size_t)s->n_spheres * sizeof(rt_sphere) : 0);
+    c->lds_bytes = sizeof(WaveLDS) + (size_t)d.node_cap * 8 + 16 + ((s->n_spheres <= RT_LDS_SPHERES_MAX) ? (size_t)s->n_spheres * sizeof(rt_sphere) : 0);
     if (c->lds_bytes > 64 * 1024) return fail(c, RT_E_INVALID, "rt_upload_scene: per-wave LDS of %zu bytes exceeds 64 KiB", c->lds_bytes);
     c->have_scene = true;
     return RT_OK;
@@ -573,7 +578,7 @@ static int render_wavefront(rt_ctx *c, const RenderArgs &ra, const rt_params *p,
     int cur = 1;
     int64_t known = n; /* upper bound of the queue length: it never grows */
     for (int64_t round = 0;; round++) {
-        hipLaunchKernelGGL(rt_wf_traverse, dim3((unsigned)((known + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, b, cur);
+        hipLaunchKernelGGL(rt_wf_traverse, dim3((unsigned)((known + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, b, cur, (p->flags & RT_F_NO_PRUNE) ? 0 : 1);
         HIPCHK(c, hipGetLastError());
         hipLaunchKernelGGL(rt_wf_shade, dim3((unsigned)((known + 255) / 256)), dim3(256), 0, c->stream, c->sc, b, ra, cur, kend, accum);
         HIPCHK(c, hipGetLastError());
@@ -709,7 +714,7 @@ int rt_intersect_rays(rt_ctx *c, const double *rays, int64_t n, int32_t *obj_id,
     int32_t *d_obj = (int32_t *)(d + b_rays + b_t + b_pn + b_al), *d_tri = d_obj + n;
     hipError_t e = hipMemcpyAsync(d_rays, rays, b_rays, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(rt_intersect_kernel, dim3((unsigned)((n + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, d_rays, n, d_obj, d_tri, d_t, d_pn, d_al);
+        hipLaunchKernelGGL(rt_intersect_kernel, dim3((unsigned)((n + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, d_rays, n, c->probe_prune ? 1 : 0, d_obj, d_tri, d_t, d_pn, d_al);
         e = hipGetLastError();
     }
     if (e == hipSuccess && obj_id) e = hipMemcpyAsync(obj_id, d_obj, b_i, hipMemcpyDeviceToHost, c->stream);
@@ -773,6 +778,13 @@ int rt_debug_stats(rt_ctx *c, uint64_t *out12) {
 int rt_debug_force_megakernel(rt_ctx *c, int on) {
     if (!c) return RT_E_INVALID;
     c->force_megakernel = on != 0;
+    return RT_OK;
+}
+
+/* not part of the public header: rt_intersect_rays with / without distance pruning (tests/ only) */
+int rt_debug_probe_prune(rt_ctx *c, int on) {
+    if (!c) return RT_E_INVALID;
+    c->probe_prune = on != 0;
     return RT_OK;
 }
 

@@ -33,8 +33,8 @@ namespace rtd {
 
 #define RT_WAVE 64
 #define RT_LDS_SPHERES_MAX 64     /* sphere lists up to this size are staged in LDS */
-#define RT_MESH_CHUNK 8           /* meshes whose roots enter the pool together */
-#define RT_NODE_SOFT 1024         /* node-item stack height up to which 64 items are popped per step */
+#define RT_MESH_CHUNK 4           /* meshes whose roots enter the pool together */
+#define RT_NODE_SOFT 512          /* node-item stack height up to which 64 items are popped per step */
 #define RT_LEAF_CAP 256           /* leaf-item stack entries */
 #define RT_LEAF_TRIGGER 24        /* pending leaf items that make the next pool step a triangle step */
 #define RT_NODE_BITS 26           /* node index bits in a node item (the ray lane takes the top 6) */
@@ -136,8 +136,9 @@ __device__ __noinline__ bool box_hit_exact(Box6 b, V3 C, V3 u) {
  * tMax and tMin are further apart than that error and tMax is not next to zero, the comparisons
  * "tMax < 0" and "tMax > tMin" come out as with true divisions. Everything else - a zero-thickness
  * box (tMax == tMin), a grazing ray, infinities or NaNs from a zero direction component - goes
- * through the true divisions. */
-__device__ __forceinline__ bool box_hit(Box6 b, V3 C, V3 u, V3 iu) {
+ * through the true divisions. tnear receives the entry parameter of the box (-infinity when the
+ * exact path decided, so that such a box is never pruned by distance). */
+__device__ __forceinline__ bool box_hit(Box6 b, V3 C, V3 u, V3 iu, double &tnear) {
     double t1x = (b.lx - C.x) * iu.x, t2x = (b.hx - C.x) * iu.x;
     double t1y = (b.ly - C.y) * iu.y, t2y = (b.hy - C.y) * iu.y;
     double t1z = (b.lz - C.z) * iu.z, t2z = (b.hz - C.z) * iu.z;
@@ -149,7 +150,11 @@ __device__ __forceinline__ bool box_hit(Box6 b, V3 C, V3 u, V3 iu) {
     /* (x - x) is 0 for finite x and NaN otherwise: one test for "all six are finite" */
     double fin = (t1x - t1x) + (t2x - t2x) + (t1y - t1y) + (t2y - t2y) + (t1z - t1z) + (t2z - t2z);
     bool sure = (fin == 0.0) && (gap > 4e-15 * mag) && (fabs(tMax) > 1e-290);
-    if (!sure) return box_hit_exact(b, C, u);
+    tnear = tMin;
+    if (!sure) {
+        tnear = -__builtin_huge_val();
+        return box_hit_exact(b, C, u);
+    }
     return !(tMax < 0) && (tMax > tMin);
 }
 
@@ -178,17 +183,18 @@ struct HitRec {
 struct WaveLDS {
     double ray[9][RT_WAVE];               /* C, u, 1/u of each lane's ray */
     unsigned long long best_t[RT_WAVE];   /* bits of the smallest accepted triangle t (> 0, so the bit order is the value order) */
+    double thr[RT_WAVE];                  /* distance beyond which nothing can change the ray's result */
     int32_t best_pos[RT_WAVE];            /* lowest triangle position among those with that t */
+    int32_t anyhit[RT_WAVE];              /* the caller only asks whether something is hit before tmax */
     int32_t mark[RT_WAVE];                /* triangle step: slot -> leaf item that starts there, or -1 */
     int32_t ex[RT_WAVE];                  /* triangle step: first slot of each leaf item */
     uint2 leaf[RT_LEAF_CAP];              /* leaf items: x = first triangle, y = count | lane << 26 */
-    uint32_t node[1];                     /* node items: record index | lane << 26; node_cap entries, then the staged spheres */
+    float leaf_t[RT_LEAF_CAP];            /* entry parameter of the leaf's box, rounded down */
+    uint2 node[1];                        /* node items: x = record index | lane << 26, y = entry parameter (float bits, rounded
+                                             down); node_cap entries, then the staged spheres */
 };
-__device__ __forceinline__ size_t wave_lds_bytes(int node_cap, int n_spheres_staged) {
-    return sizeof(WaveLDS) + (size_t)node_cap * 4 + 16 + (size_t)n_spheres_staged * sizeof(rt_sphere);
-}
 __device__ __forceinline__ const rt_sphere *lds_spheres(const WaveLDS *w, int node_cap) {
-    size_t off = (offsetof(WaveLDS, node) + (size_t)node_cap * 4 + 15) & ~(size_t)15;
+    size_t off = (offsetof(WaveLDS, node) + (size_t)node_cap * 8 + 15) & ~(size_t)15;
     return reinterpret_cast<const rt_sphere *>(reinterpret_cast<const unsigned char *>(w) + off);
 }
 
@@ -230,11 +236,20 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+/* Pruning margin: a box is skipped when its entry parameter exceeds the ray's threshold by more than
+ * one part in a million. The triangle parameters the reference computes (raytracer.cpp:681-686) carry a
+ * relative error of about 6e-16 / |cos(ray, normal)|; an accepted triangle whose computed t falls
+ * outside its own box by more than 1e-6 would need |cos| < 1e-9, and accepted hits have a cos-weighted
+ * distribution, so this happens about once in 1e18 hits. RT_F_NO_PRUNE visits everything. */
+#define RT_PRUNE_SLACK 1.000001
+
 /* Scene::intersect, raytracer.cpp:930-951. Called by all 64 lanes together; `active` lanes get the
- * closest hit of their ray (C, u). */
+ * closest hit of their ray (C, u). tmax / anyhit describe what the caller will do with the answer:
+ * anyhit = it only tests "hit && t < tmax" (the shadow test, raytracer.cpp:1073), so hits at or beyond
+ * tmax need not be found and the first one below it settles the ray. */
 template <bool CNT>
 __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w, const rt_sphere *sph, bool active, V3 C, V3 u,
-                                                   HitRec &h, Cnt &cnt) {
+                                                   double tmax, bool anyhit, bool prune, HitRec &h, Cnt &cnt) {
     const int lane = lane_id();
     h.t = 1E10;
     h.obj = INT32_MAX;
@@ -266,12 +281,24 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
     }
     if (sc.n_meshes == 0) return h.obj != INT32_MAX;
 
+    /* Mesh hits are accepted only below t0 = min(1E9, sphere hit, tmax): TriangleMesh::intersect starts at
+     * t = 1E9 (raytracer.cpp:647), a mesh hit beyond the closest sphere loses in Scene::intersect (:938)
+     * and one beyond tmax cannot matter to the caller. A mesh hit AT t0 is still recorded (tie rules). */
+    double t0 = 1E9;
+    if (prune) {
+        if (h.t < t0) t0 = h.t;
+        if (tmax < t0) t0 = tmax;
+        if (!(t0 > 0)) t0 = 0; /* also turns -0.0 into +0.0: the bit pattern must order like the value */
+    }
     V3 iu = mk(1.0 / u.x, 1.0 / u.y, 1.0 / u.z);
     w->ray[0][lane] = C.x; w->ray[1][lane] = C.y; w->ray[2][lane] = C.z;
     w->ray[3][lane] = u.x; w->ray[4][lane] = u.y; w->ray[5][lane] = u.z;
     w->ray[6][lane] = iu.x; w->ray[7][lane] = iu.y; w->ray[8][lane] = iu.z;
-    w->best_t[lane] = (unsigned long long)__double_as_longlong(1E9); /* t = 1E9 before the first triangle, :647 */
+    w->best_t[lane] = (unsigned long long)__double_as_longlong(t0);
     w->best_pos[lane] = INT32_MAX;
+    w->thr[lane] = prune ? t0 * RT_PRUNE_SLACK : __builtin_huge_val();
+    w->anyhit[lane] = (anyhit && prune) ? 1 : 0;
+    const double my_thr = prune ? t0 * RT_PRUNE_SLACK : __builtin_huge_val();
 
     int n_nodes = 0, n_leaves = 0; /* wave-uniform stack heights */
     int mi = 0;
@@ -283,19 +310,24 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
             const rt_mesh &m = sc.meshes[mi];
             mi++;
             bool pass = false;
+            double tn = 0;
             if (active) {
                 if (CNT) cnt.box_tests++;
-                pass = box_hit(ldbox(m.root_box), C, u, iu);
+                pass = box_hit(ldbox(m.root_box), C, u, iu, tn);
                 if (CNT && pass) cnt.mesh_calls++;
+                pass = pass && !(tn > my_thr);
             }
             const unsigned long long bal = __ballot(pass);
             if (bal == 0ull) continue;
             const int r = rank_in(bal);
             if (m.root_count == 0) {
-                if (pass) w->node[n_nodes + r] = (uint32_t)m.root | ((uint32_t)lane << RT_NODE_BITS);
+                if (pass) w->node[n_nodes + r] = make_uint2((uint32_t)m.root | ((uint32_t)lane << RT_NODE_BITS), __float_as_uint(__double2float_rd(tn)));
                 n_nodes = uni(n_nodes + __popcll(bal));
             } else { /* the root is itself a leaf */
-                if (pass) w->leaf[n_leaves + r] = make_uint2((uint32_t)m.root, (uint32_t)m.root_count | ((uint32_t)lane << 26));
+                if (pass) {
+                    w->leaf[n_leaves + r] = make_uint2((uint32_t)m.root, (uint32_t)m.root_count | ((uint32_t)lane << 26));
+                    w->leaf_t[n_leaves + r] = __double2float_rd(tn);
+                }
                 n_leaves = uni(n_leaves + __popcll(bal));
             }
         }
@@ -309,22 +341,27 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
                  * (first, count) ranges; a prefix sum of the counts gives every item its slots, slot s (=
                  * lane s) finds its item through a marker + running maximum, and tests triangle
                  * first + (s - first slot of the item). Items used up are popped, the one cut by slot 64 is
-                 * shortened in place and becomes the new top. */
+                 * shortened in place and becomes the new top. A leaf that has fallen behind its ray's
+                 * threshold since it was pushed counts as empty. */
                 const int m = n_leaves < RT_WAVE ? n_leaves : RT_WAVE;
                 uint2 it = make_uint2(0u, 0u);
-                if (lane < m) it = w->leaf[n_leaves - 1 - lane];
-                const int cntl = (lane < m) ? (int)(it.y & 0x3FFFFFFu) : 0;
+                int cntl = 0;
+                if (lane < m) {
+                    it = w->leaf[n_leaves - 1 - lane];
+                    cntl = (int)(it.y & 0x3FFFFFFu);
+                    if ((double)w->leaf_t[n_leaves - 1 - lane] > w->thr[it.y >> 26]) cntl = 0;
+                }
                 const int incl = wave_scan_add(cntl);
                 const int excl = incl - cntl;
                 const int total = __builtin_amdgcn_readlane(incl, 63);
                 const int take = total < RT_WAVE ? total : RT_WAVE;
                 w->mark[lane] = -1;
                 wave_sync();
-                if (lane < m && excl < RT_WAVE) w->mark[excl] = lane;
+                if (cntl > 0 && excl < RT_WAVE) w->mark[excl] = lane;
                 w->ex[lane] = excl;
                 wave_sync();
                 const int j = wave_scan_max(w->mark[lane]);
-                const bool have = lane < take; /* then j >= 0: slot 0 carries the marker of item 0 */
+                const bool have = lane < take; /* then j >= 0: slot 0 carries the marker of the first non-empty item */
                 uint2 itj = make_uint2(0u, 0u);
                 int exj = 0;
                 if (have) { itj = w->leaf[n_leaves - 1 - j]; exj = w->ex[j]; }
@@ -343,7 +380,7 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
                     if (CNT) cnt.tris++;
                     V3 rc = mk(w->ray[0][rl], w->ray[1][rl], w->ray[2][rl]);
                     V3 ru = mk(w->ray[3][rl], w->ray[4][rl], w->ray[5][rl]);
-                    acc = tri_test(sc.tris + tri, rc, ru, beta, gamma, lt) && (lt < 1E9);
+                    acc = tri_test(sc.tris + tri, rc, ru, beta, gamma, lt);
                 }
                 if (__ballot(acc) != 0ull) {
                     /* keep (min t, then min position) per ray. LDS executes one wave's instructions in
@@ -357,7 +394,10 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
                     if (acc) {
                         const unsigned long long cur = w->best_t[rl];
                         mine = (tb == cur);
-                        if (mine && old > cur) w->best_pos[rl] = INT32_MAX; /* this lane lowered the minimum */
+                        if (mine && old > cur) { /* this lane lowered the minimum */
+                            w->best_pos[rl] = INT32_MAX;
+                            if (prune) w->thr[rl] = w->anyhit[rl] ? 0.0 : lt * RT_PRUNE_SLACK;
+                        }
                     }
                     wave_sync();
                     if (mine) atomicMin(&w->best_pos[rl], (int32_t)tri);
@@ -365,48 +405,66 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
                 wave_sync();
                 if (CNT) { uint64_t t = RT_STAMP(); cnt.cyc_leaf += t - st0; st0 = t; cnt.leaf_steps++; cnt.leaf_lanes += (uint64_t)k; }
             } else {
-                /* one BVH record per lane: test both child boxes (raytracer.cpp:656-665), push the hit ones */
-                /* Up to 64 records per step while the stack is below RT_NODE_SOFT (a step can add one
+                /* one BVH record per lane: test both child boxes (raytracer.cpp:656-665), push the hit ones.
+                 * Up to 64 records per step while the stack is below RT_NODE_SOFT (a step can add one
                  * entry per record popped); above it one record per step, a plain depth-first descent
                  * that needs at most max_depth + 1 entries more. */
                 int k = n_nodes < RT_WAVE ? n_nodes : RT_WAVE;
                 const int room = RT_NODE_SOFT - n_nodes;
                 if (k > room) k = room > 1 ? room : 1;
-                const bool have = lane < k;
-                uint32_t it = 0;
+                bool have = lane < k;
+                uint2 it = make_uint2(0u, 0u);
                 if (have) it = w->node[n_nodes - 1 - lane];
                 n_nodes -= k;
                 wave_sync();
-                const int rl = (int)(it >> RT_NODE_BITS);
+                const int rl = (int)(it.x >> RT_NODE_BITS);
                 bool pnl = false, pnr = false, pll = false, plr = false;
                 int32_t L = 0, R = 0, nL = 0, nR = 0;
+                double tl = 0, tr = 0;
+                double thr = 0;
+                if (have) {
+                    thr = w->thr[rl];
+                    have = !((double)__uint_as_float(it.y) > thr); /* fallen behind the threshold since it was pushed */
+                }
                 if (have) {
                     /* the whole 128-byte record in one batch of loads, before either box is tested */
-                    const rt_bvh_node *nd = sc.nodes + (it & ((1u << RT_NODE_BITS) - 1u));
+                    const rt_bvh_node *nd = sc.nodes + (it.x & ((1u << RT_NODE_BITS) - 1u));
                     const Box6 bl = ldbox(nd->boxL), br = ldbox(nd->boxR);
+                    L = nd->L; R = nd->R; nL = nd->nL; nR = nd->nR;
                     if (CNT) { cnt.nodes++; cnt.box_tests += 2; }
                     V3 rc = mk(w->ray[0][rl], w->ray[1][rl], w->ray[2][rl]);
                     V3 ru = mk(w->ray[3][rl], w->ray[4][rl], w->ray[5][rl]);
                     V3 ri = mk(w->ray[6][rl], w->ray[7][rl], w->ray[8][rl]);
-                    L = nd->L; R = nd->R; nL = nd->nL; nR = nd->nR;
-                    const bool hl = box_hit(bl, rc, ru, ri);
-                    const bool hr = box_hit(br, rc, ru, ri);
+                    const bool hl = box_hit(bl, rc, ru, ri, tl) && !(tl > thr);
+                    const bool hr = box_hit(br, rc, ru, ri, tr) && !(tr > thr);
                     pnl = hl && nL == 0; pll = hl && nL > 0;
                     pnr = hr && nR == 0; plr = hr && nR > 0;
+                    /* the nearer child goes on top of the stack: it is popped first */
+                    if (pnl && pnr && tl < tr) {
+                        const int32_t ti = L; L = R; R = ti;
+                        const double td = tl; tl = tr; tr = td;
+                    }
                 }
                 const unsigned long long b0 = __ballot(pnl), b1 = __ballot(pnr), b2 = __ballot(pll), b3 = __ballot(plr);
                 const int c0 = __popcll(b0), c1 = __popcll(b1);
                 if (n_nodes + c0 + c1 > sc.node_cap) { /* cannot happen for a validated scene; never write past the stack */
                     if (lane == 0) atomicOr(sc.overflow, 1);
-                    pnl = pnr = false;
                 } else {
-                    if (pnl) w->node[n_nodes + rank_in(b0)] = (uint32_t)L | ((uint32_t)rl << RT_NODE_BITS);
-                    if (pnr) w->node[n_nodes + c0 + rank_in(b1)] = (uint32_t)R | ((uint32_t)rl << RT_NODE_BITS);
+                    if (pnl) w->node[n_nodes + rank_in(b0)] = make_uint2((uint32_t)L | ((uint32_t)rl << RT_NODE_BITS), __float_as_uint(__double2float_rd(tl)));
+                    if (pnr) w->node[n_nodes + c0 + rank_in(b1)] = make_uint2((uint32_t)R | ((uint32_t)rl << RT_NODE_BITS), __float_as_uint(__double2float_rd(tr)));
                     n_nodes = uni(n_nodes + c0 + c1);
                 }
                 const int c2 = __popcll(b2);
-                if (pll) w->leaf[n_leaves + rank_in(b2)] = make_uint2((uint32_t)L, (uint32_t)nL | ((uint32_t)rl << 26));
-                if (plr) w->leaf[n_leaves + c2 + rank_in(b3)] = make_uint2((uint32_t)R, (uint32_t)nR | ((uint32_t)rl << 26));
+                if (pll) {
+                    const int q = n_leaves + rank_in(b2);
+                    w->leaf[q] = make_uint2((uint32_t)L, (uint32_t)nL | ((uint32_t)rl << 26));
+                    w->leaf_t[q] = __double2float_rd(tl);
+                }
+                if (plr) {
+                    const int q = n_leaves + c2 + rank_in(b3);
+                    w->leaf[q] = make_uint2((uint32_t)R, (uint32_t)nR | ((uint32_t)rl << 26));
+                    w->leaf_t[q] = __double2float_rd(tr);
+                }
                 n_leaves = uni(n_leaves + c2 + __popcll(b3));
                 wave_sync();
                 if (CNT) { uint64_t t = RT_STAMP(); cnt.cyc_node += t - st0; st0 = t; cnt.node_steps++; cnt.node_lanes += (uint64_t)k; }
@@ -417,11 +475,11 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
     if (active) {
         const double tm = __longlong_as_double((long long)w->best_t[lane]);
         const int32_t pos = w->best_pos[lane];
-        if (tm < 1E9 && pos != INT32_MAX) {
-            const int32_t mi = sc.tris[pos].mesh;
-            const int32_t oid = sc.meshes[mi].object_id;
+        if (pos != INT32_MAX) {
+            const int32_t mi2 = sc.tris[pos].mesh;
+            const int32_t oid = sc.meshes[mi2].object_id;
             if (tm < h.t || (tm == h.t && oid < h.obj)) {
-                h.t = tm; h.obj = oid; h.prim = pos; h.mesh = mi;
+                h.t = tm; h.obj = oid; h.prim = pos; h.mesh = mi2;
                 double lt;
                 (void)tri_test(sc.tris + pos, C, u, h.beta, h.gamma, lt); /* alpha, beta, gamma of the winner (:683-685) */
             }
@@ -699,7 +757,8 @@ __device__ __forceinline__ V3 trace_pixel(const DScene &sc, WaveLDS *w, const rt
         if (__ballot(!q.finished) == 0ull) break;
         if (CNT) cnt.cyc_fresh += RT_STAMP() - sp0;
         HitRec h;
-        bool inter = scene_closest_wave<CNT>(sc, w, sph, !q.finished, q.rC, q.ru, h, cnt);
+        bool inter = scene_closest_wave<CNT>(sc, w, sph, !q.finished, q.rC, q.ru, q.shadow ? q.sh_limit : 1E10, q.shadow,
+                                             !(ra.p.flags & RT_F_NO_PRUNE), h, cnt);
         if (CNT) sp0 = RT_STAMP();
         if (!q.finished) path_advance<CNT>(sc, sph, ra, q, inter, h, cnt);
         if (CNT) cnt.cyc_shade += RT_STAMP() - sp0;

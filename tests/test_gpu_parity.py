@@ -16,6 +16,14 @@ def _scene_pair(ob, scenes, builder, **kw):
     return s, cam, flags, ob.OracleScene(objs, s.I, s.L)
 
 
+@pytest.fixture(params=["prune", "noprune"])
+def probe_mode(request, gpu, rta):
+    """rt_intersect_rays with distance pruning (the default) and visiting every node as the reference does"""
+    rta.lib.rt_debug_probe_prune(gpu._h, 1 if request.param == "prune" else 0)
+    yield request.param
+    rta.lib.rt_debug_probe_prune(gpu._h, 1)
+
+
 def _check_hits(g, o):
     assert np.array_equal(g["obj"], o["obj"])
     assert np.array_equal(g["tri"], o["tri"])
@@ -51,14 +59,14 @@ def test_wave_scans(gpu, rta):
 
 
 @pytest.mark.parametrize("W", [64, 257])
-def test_primary_hits_sphere_room(gpu, rta, scenes, ob, W):
+def test_primary_hits_sphere_room(gpu, rta, scenes, ob, W, probe_mode):
     s, cam, flags, orc = _scene_pair(ob, scenes, scenes.sphere_room, W=W)
     gpu.upload(s)
     rays, _ = ob.primary_rays(cam, W, W)
     _check_hits(gpu.intersect_rays(rays), orc.intersect_rays(rays))
 
 
-def test_primary_hits_mesh_room(gpu, rta, scenes, ob):
+def test_primary_hits_mesh_room(gpu, rta, scenes, ob, probe_mode):
     W = 160
     s, cam, flags, orc = _scene_pair(ob, scenes, scenes.mesh_room, W=W, n_tris=30000, tex_size=128)
     gpu.upload(s)
@@ -68,7 +76,7 @@ def test_primary_hits_mesh_room(gpu, rta, scenes, ob):
     _check_hits(g, o)
 
 
-def test_random_rays_battle(gpu, rta, scenes, ob):
+def test_random_rays_battle(gpu, rta, scenes, ob, probe_mode):
     """incoherent rays from inside the room against the 12-mesh scene (reduced triangle count)"""
     s, cam, flags, meta = scenes.battle(W=64, tri_scale=0.1, tex_size=64)
     orc = ob.OracleScene(scenes.export_objects(s), s.I, s.L)
@@ -84,7 +92,7 @@ def test_random_rays_battle(gpu, rta, scenes, ob):
     _check_hits(g, o)
 
 
-def test_degenerate_rays(gpu, rta, scenes, ob):
+def test_degenerate_rays(gpu, rta, scenes, ob, probe_mode):
     """axis-parallel directions (division by zero in the slab test), zero direction, NaN"""
     s, cam, flags, orc = _scene_pair(ob, scenes, scenes.mesh_room, W=64, n_tris=3000, tex_size=32)
     gpu.upload(s)
@@ -145,7 +153,7 @@ def test_counters_match_oracle(gpu, rta, scenes, ob):
     W = 64
     s, cam, flags, orc = _scene_pair(ob, scenes, scenes.mesh_room, W=W, n_tris=5000, tex_size=32)
     gpu.upload(s)
-    p = rta.make_params(W, W, 2, flags=rta.RT_F_COUNTERS)
+    p = rta.make_params(W, W, 2, flags=rta.RT_F_COUNTERS | rta.RT_F_NO_PRUNE)
     gpu.reset_counters()
     gpu.accum_clear(W, W)
     gpu.render(cam, p)
@@ -156,6 +164,27 @@ def test_counters_match_oracle(gpu, rta, scenes, ob):
     assert gc["paths"] == oc["paths"] == W * W * 2
     for k in ("rays", "box_tests", "nodes", "tris", "mesh_calls", "diffuse", "specular"):
         assert abs(gc[k] - oc[k]) <= 1e-4 * oc[k] + 50, (k, gc[k], oc[k])
+
+
+def test_pruning_changes_work_not_results(gpu, rta, scenes, ob):
+    """default (pruned, any-hit shadow rays) render == RT_F_NO_PRUNE render bit for bit, with fewer node visits"""
+    W = 96
+    s, cam, flags, orc = _scene_pair(ob, scenes, scenes.mesh_room, W=W, n_tris=20000, tex_size=64)
+    gpu.upload(s)
+    out = {}
+    for name, fl in (("prune", 0), ("noprune", rta.RT_F_NO_PRUNE)):
+        gpu.accum_clear(W, W)
+        gpu.render(cam, rta.make_params(W, W, 3, flags=fl))
+        out[name] = gpu.accum_download(W, W)
+        gpu.reset_counters()
+        gpu.accum_clear(W, W)
+        gpu.render(cam, rta.make_params(W, W, 3, flags=fl | rta.RT_F_COUNTERS))
+        out[name + "_cnt"] = gpu.counters()
+        assert np.array_equal(gpu.accum_download(W, W), out[name], equal_nan=True)  # single-kernel form == wavefront form
+    assert np.array_equal(out["prune"], out["noprune"], equal_nan=True)
+    assert out["prune_cnt"]["rays"] == out["noprune_cnt"]["rays"]
+    assert out["prune_cnt"]["nodes"] < out["noprune_cnt"]["nodes"]
+    assert out["prune_cnt"]["tris"] < out["noprune_cnt"]["tris"]
 
 
 def test_errors(gpu, rta, scenes):
