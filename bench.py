@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=2)
     ap.add_argument("--out-png", default="")
-    ap.add_argument("--mode", default="default", choices=["default", "megakernel"], help="A/B switch: single-kernel render loop instead of the wavefront one")
+    ap.add_argument("--mode", default="default", choices=["default", "wavefront"], help="A/B switch: two-kernel wavefront render loop instead of the single persistent kernel")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -82,10 +82,10 @@ def main():
     W = H = args.size
     t0 = time.time()
     scene, cam, flags, meta = scenes.battle(W=W)
+    if args.mode == "wavefront":
+        flags |= rta.RT_F_WAVEFRONT
     r = rta.Renderer(local_rank)
     r.upload(scene)
-    if args.mode == "megakernel":
-        rta.lib.rt_debug_force_megakernel(r._h, 1)
     info = scene.flat_info()
     setup_s = time.time() - t0
 

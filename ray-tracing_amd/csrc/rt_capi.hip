@@ -306,7 +306,6 @@ struct rt_ctx {
     int accW = 0, accH = 0;
     rt_counters *d_counters = nullptr;
     int *d_overflow = nullptr;
-    bool force_megakernel = false;
     bool probe_prune = true;
     /* wavefront state */
     WfBuf wf{};
@@ -615,8 +614,8 @@ int rt_render(rt_ctx *c, const rt_camera *cam, const rt_params *p, double *accum
     c->last_launches = 0;
     c->timed = false;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    if ((p->flags & RT_F_COUNTERS) || c->force_megakernel) {
-        /* single-kernel form: the counted variant, and an A/B switch for measurements */
+    if ((p->flags & RT_F_COUNTERS) || !(p->flags & RT_F_WAVEFRONT)) {
+        /* single persistent kernel (default, and the only counted variant) */
         for (int k = 0; k < p->spp; k += kSppPerLaunch) {
             const int nk = (p->spp - k < kSppPerLaunch) ? (p->spp - k) : kSppPerLaunch;
             if (p->flags & RT_F_COUNTERS)
@@ -771,13 +770,6 @@ int rt_debug_stats(rt_ctx *c, uint64_t *out12) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(out12, reinterpret_cast<uint64_t *>(c->d_counters) + 8, 12 * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return RT_OK;
-}
-
-/* not part of the public header: A/B switch between the wavefront and the single-kernel render (tools/ only) */
-int rt_debug_force_megakernel(rt_ctx *c, int on) {
-    if (!c) return RT_E_INVALID;
-    c->force_megakernel = on != 0;
     return RT_OK;
 }
 

@@ -1,0 +1,68 @@
+"""CPU, world_size 2 over gloo: the samples-per-pixel sharding plan and the sum-reduction that bench.py
+runs over RCCL. The per-rank renderer here is the CPU oracle (no GPU in this container); what is under
+test is the plan: disjoint global sample indices per (step, rank), one reduce to rank 0, same image as
+one process rendering all the samples."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rta = importlib.import_module("ray-tracing_amd")
+    scenes = importlib.import_module("ray-tracing_amd.scenes")
+    par = importlib.import_module("ray-tracing_amd.parallel")
+    from oracle import bindings as ob
+    W, steps, spp_step = 24, 2, 3
+    s, cam, flags = scenes.sphere_room(W)
+    orc = ob.OracleScene(scenes.export_objects(s), s.I, s.L)
+    acc = np.zeros((W, W, 3))
+    for step in range(steps):
+        off = par.shard_offset(step, world, rank, spp_step)
+        orc.render(cam, rta.make_params(W, W, spp_step, spp_offset=off), accum=acc, n_threads=1)
+    t = torch.from_numpy(acc)
+    par.reduce_to_root(t, world)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "reduced.npy"), t.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_spp_sharding_two_ranks(tmp_path, rta, scenes, ob):
+    import torch.multiprocessing as mp
+    par = importlib.import_module("ray-tracing_amd.parallel")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(os.path.join(str(tmp_path), "reduced.npy"))
+    W, steps, spp_step = 24, 2, 3
+    s, cam, flags = scenes.sphere_room(W)
+    orc = ob.OracleScene(scenes.export_objects(s), s.I, s.L)
+    total = par.total_spp(steps, 2, spp_step)
+    want = orc.render(cam, rta.make_params(W, W, total), n_threads=2)
+    # same samples, different order of the final additions
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-9)
+    assert np.array_equal(ob.resolve(got, total), ob.resolve(want, total))
+
+
+def test_shard_offsets_are_disjoint():
+    par = importlib.import_module("ray-tracing_amd.parallel")
+    for world in (1, 2, 4, 8):
+        seen = set()
+        for step in range(5):
+            for rank in range(world):
+                off = par.shard_offset(step, world, rank, 16)
+                block = set(range(off, off + 16))
+                assert not (seen & block)
+                seen |= block
+        assert seen == set(range(par.total_spp(5, world, 16)))

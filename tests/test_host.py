@@ -1,0 +1,138 @@
+"""CPU: the product's host side (C++ classes behind include/rt_amd_host.h) - OBJ reader, mesh transforms,
+BVH build, camera basis, flattening - against the golden outputs of the real reference, and against the
+real reference itself where it is built. No GPU call is made."""
+import ctypes as C
+import hashlib
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = np.load(os.path.join(HERE, "golden", "reference_outputs.npz"))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_library_exports_every_declared_symbol(rta):
+    declared = []
+    for h in ("rt_amd.h", "rt_amd_host.h"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared += re.findall(r"\b(rt_[a-z_0-9]+|rth_[a-z_0-9]+)\s*\(", text)
+    declared = sorted(set(declared))
+    assert len(declared) >= 35
+    assert set(declared) == set(rta.RT_SYMBOLS + rta.RTH_SYMBOLS)
+    for name in declared:
+        assert hasattr(rta.lib, name), name
+    assert b"gfx950" in rta.lib.rt_version()
+
+
+def test_pod_layouts_match_the_header(rta):
+    assert C.sizeof(rta.rt_camera) == 16 * 8
+    assert C.sizeof(rta.rt_params) == 4 * 4 + 8 + 4 + 4 + 3 * 8 + 16
+    assert C.sizeof(rta.rt_counters) == 8 * 8
+
+
+def test_camera_basis(rta):
+    for key, args in (("camera_default_1024", ((0, 30, 55), 60.0, -25.0, 0.0, 1024)), ("camera_m30_10_512", ((0, 30, 55), 60.0, -30.0, 10.0, 512))):
+        c = rta.make_camera(*args)
+        got = np.array(list(c.right) + list(c.up) + list(c.view) + [c.zdist])
+        assert np.allclose(got, GOLD[key], rtol=1e-15, atol=1e-16)  # cos/sin/tan of this machine's libm
+    c = rta.make_camera()
+    assert (c.focus, c.aa_sigma, c.dof_sigma) == (55.0, 0.25, 0.01)
+    p = rta.make_params(64, 32, 5)
+    assert (p.max_rebond, p.ior, p.epsilon, p.shadow_bias, p.seed) == (10, 1.4, 1e-5, 1e-4, 10)
+
+
+def test_obj_reader(rta):
+    m = rta.TriangleMesh()
+    m.readOBJ(os.path.join(HERE, "golden", "reader_cases.obj"))
+    v, n, uv, ix, _ = m.arrays()
+    assert np.array_equal(v, GOLD["reader_verts"]) and np.array_equal(n, GOLD["reader_normals"]) and np.array_equal(uv, GOLD["reader_uvs"])
+    assert np.array_equal(ix, GOLD["reader_idx"]), (ix, GOLD["reader_idx"])
+    assert len(ix) == 2 + 1 + 3 + 2 + 1 + 3 + 1 + 2 + 2 + 1 + 1
+    with pytest.raises(rta.RTError):
+        rta.TriangleMesh().readOBJ("/nonexistent/file.obj")
+
+
+def test_transform_chains_and_bvh(rta):
+    mg = importlib.import_module("tests.golden.make_golden")
+    for name, ops in mg.MESH_CHAINS.items():
+        v, n, uv, ix = mg.chain_mesh(name)
+        m = rta.TriangleMesh().set_raw(v, n, uv, ix)
+        for op in ops:
+            getattr(m, op[0])(*op[1:])
+        m.buildBVH()
+        v2, n2, uv2, ix2, perm = m.arrays()
+        boxes, dfl = m.bvh_dump()
+        hv, hn, hi, hp, hb, hd = GOLD["chain_%s" % name]
+        assert np.array_equal(v2[:4], GOLD["chain_%s_v0" % name])
+        assert sha(v2) == hv and sha(n2) == hn, name
+        assert sha(ix2) == hi and sha(perm) == hp, name
+        assert len(boxes) == GOLD["chain_%s_nodes" % name][0] and sha(boxes) == hb and sha(dfl) == hd, name
+
+
+def test_zoom_takes_an_int(rta):
+    """zoom(0.8) is zoom(0): the argument is an int (raytracer.cpp:840, :1285); zoom(k) scales by 1 + k"""
+    v = np.array([[0.25, 0.5, 1.0], [1.5, -2.0, 0.125], [0.1, 0.2, 0.3]])
+    n = np.array([[0, 0, 1.0]] * 3)
+    ix = np.array([[0, 1, 2, 0, 0, 0, 0, 1, 2, 0]], np.int32)
+    m = rta.TriangleMesh().set_raw(v, n, np.zeros((1, 2)), ix)
+    m.zoom(0.8)
+    assert np.array_equal(m.arrays()[0], v)
+    m.zoom(4)
+    assert np.array_equal(m.arrays()[0], v + 4 * v)
+    m.translate(1, 0)  # distance 0 mirrors the axis (raytracer.cpp:786-792)
+    assert np.array_equal(m.arrays()[0][:, 1], -(v + 4 * v)[:, 1])
+
+
+def test_flatten_layout(rta, scenes):
+    s, cam, flags, meta = scenes.battle(W=64, tri_scale=0.02, tex_size=16)
+    info = s.flat_info()
+    assert info["n_spheres"] == 6 and info["n_meshes"] == 12
+    assert info["n_tris"] == sum(m["nt"] for m in meta)
+    assert info["bytes"] > info["n_tris"] * (80 + 128)
+    bad = rta.Scene()
+    bad.add(rta.Sphere((0, 0, 0), 1, (1, 1, 1)))
+    bad.add(rta.TriangleMesh())  # no triangles, no BVH
+    with pytest.raises(rta.RTError):
+        bad.flat_info()
+
+
+def test_missing_extension_fails_loudly(tmp_path):
+    """the product has no CPU fallback: without the HIP library the import raises"""
+    import shutil
+    import subprocess
+    import sys
+    dst = tmp_path / "ray-tracing_amd"
+    shutil.copytree(os.path.join(ROOT, "ray-tracing_amd"), dst, ignore=shutil.ignore_patterns("*.so", "__pycache__"))
+    code = "import importlib,sys; sys.path.insert(0, %r); importlib.import_module('ray-tracing_amd')" % str(tmp_path)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode != 0 and "HIP extension not built" in r.stderr
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/objects"), reason="reference assets absent")
+def test_host_against_the_real_reference_on_real_assets(rta, ob):
+    """readOBJ + the jet's transform chain (with its int truncation) + buildBVH on the real OBJ files"""
+    if not ob.have_trueref():
+        pytest.skip("oracle/_ref not built")
+    mg = importlib.import_module("tests.golden.make_golden")
+    for rel, chain in (("airplane/10593_Fighter_Jet_SG_v1_iterations-2.obj", "fighter_jet"), ("dumbell/10499_Dumbells_v1_L3.obj", "t70"),
+                       ("soldiers/rifle_soldier/14070_WWII_Soldier_with_Rife_v1_L1.obj", "rifle_soldier")):
+        path = os.path.join("/root/reference/objects", rel)
+        ops = mg.MESH_CHAINS[chain]
+        t = ob.TrueRefScene([dict(kind="mesh", obj_path=path, ops=ops, albedo=(1, 1, 1), mirror=False, transp=False)], 1.0, (0, 0, 0))
+        m = rta.TriangleMesh().readOBJ(path)
+        for op in ops:
+            getattr(m, op[0])(*op[1:])
+        m.buildBVH()
+        for a, b in zip(m.arrays(), t.mesh_arrays(0)):
+            assert np.array_equal(a, b), rel
+        for a, b in zip(m.bvh_dump(), t.bvh_dump(0)):
+            assert np.array_equal(a, b), rel

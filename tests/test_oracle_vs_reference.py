@@ -1,0 +1,110 @@
+"""CPU, only where /root/reference exists: the oracle against the REAL reference classes
+(oracle/_ref/libref_true.so) on the same inputs, bit for bit. This is what pins the oracle; the
+golden fixtures carry the same comparison to machines without the reference."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import bindings as ob_mod
+
+pytestmark = pytest.mark.skipif(not ob_mod.have_trueref(), reason="oracle/_ref not built (needs /root/reference)")
+
+REF_OBJECTS = "/root/reference/objects"
+
+
+def _pair(scenes, ob, builder, **kw):
+    res = builder(**kw)
+    s, cam = res[0], res[1]
+    objs = scenes.export_objects(s)
+    return s, cam, ob.OracleScene(objs, s.I, s.L), ob.TrueRefScene(objs, s.I, s.L)
+
+
+def _same_hits(a, b):
+    for k in ("obj", "tri", "t", "P", "N", "albedo"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("name,kw", [("sphere_room", dict(W=64)), ("mesh_room", dict(W=64, n_tris=4000, tex_size=32)),
+                                     ("battle", dict(W=48, tri_scale=0.03, tex_size=32))])
+def test_intersect_and_radiance_bit_identical(rta, scenes, ob, name, kw):
+    s, cam, o, t = _pair(scenes, ob, getattr(scenes, name), **kw)
+    W = kw["W"]
+    rays, _ = ob.primary_rays(cam, W, W)
+    _same_hits(o.intersect_rays(rays), t.intersect_rays(rays))
+    ijk = np.array([(i, j, k) for i in range(0, W, 3) for j in range(0, W, 3) for k in range(3)], np.int32)
+    p = rta.make_params(W, W, 3)
+    assert np.array_equal(o.sample_radiance(cam, p, ijk), t.sample_radiance(cam, p, ijk), equal_nan=True)
+    # the pixel loop and the tone map
+    p2 = rta.make_params(W, W, 2, rect=(8, 8, 24, 24))
+    ao, at = o.render(cam, p2, n_threads=2), t.render(cam, p2)
+    assert np.array_equal(ao, at, equal_nan=True)
+    assert np.array_equal(ob.resolve(ao, 2), ob.trueref_resolve(at, 2))
+
+
+def test_axis_aligned_normals_like_the_reference(rta, scenes, ob):
+    """random_cos builds a zero tangent for some axis-aligned normals (raytracer.cpp:120-135): the bounce direction is NaN,
+    the NaN ray hits nothing, and the vertex keeps only its direct light. Whatever comes out must equal the reference."""
+    # slightly tilted: a flat axis-aligned quad has a zero-thickness box, which the slab test never reports as hit
+    v = np.array([[-20, -9.7, -20], [20, -9.3, -20], [20, -9.3, 20], [-20, -9.7, 20]], float)
+    uv = np.zeros((1, 2))
+    ix = np.array([[0, 1, 2, 0, 0, 0, 0, 0, 0, 0], [0, 2, 3, 0, 0, 0, 0, 0, 0, 0]], np.int32)
+    cam = rta.make_camera(W=32)
+    p = rta.make_params(32, 32, 2)
+    lit = 0
+    for normal in [(0, -1, 0), (0, 1, 0), (0, 0, 1), (0, 0, -1), (1, 0, 0), (-1, 0, 0)]:
+        n = np.array([normal], float)
+        objs = [dict(kind="sphere", O=(-10, 50, 40), R=5, albedo=(1, 1, 1), mirror=False, transp=False),
+                dict(kind="mesh", verts=v, normals=n, uvs=uv, idx=ix, albedo=(1, 1, 1), mirror=False, transp=False)]
+        o, t = ob.OracleScene(objs, 6e9, (-10, 50, 40)), ob.TrueRefScene(objs, 6e9, (-10, 50, 40))
+        ao, at = o.render(cam, p), t.render(cam, p)
+        assert np.array_equal(ao, at, equal_nan=True), normal
+        assert np.array_equal(ob.resolve(ao, 2), ob.trueref_resolve(at, 2))
+        lit += int((np.nan_to_num(at, nan=1.0) != 0).any())
+    assert lit >= 2
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_OBJECTS), reason="reference assets absent")
+def test_real_obj_with_stb_texture(rta, scenes, ob):
+    """the rifle soldier as the reference loads it (readOBJ + stb_image JPEG decode + the battle-scene transform
+    chain, raytracer.cpp:1243-1251), handed to the oracle as raw arrays"""
+    obj = os.path.join(REF_OBJECTS, "soldiers/rifle_soldier/14070_WWII_Soldier_with_Rife_v1_L1.obj")
+    jpg = os.path.join(REF_OBJECTS, "soldiers/rifle_soldier/14070_WWII_Soldier_with_Rifle_diff.jpg")
+    ops = [("zoom", 4), ("rotate", 1, 2), ("rotate", 0, 2), ("translate", 1, -10), ("rotateAroundAxe", 1, -30), ("translate", 0, 5), ("translate", 2, 10)]
+    light = dict(kind="sphere", O=(-10, 50, 40), R=5, albedo=(1, 1, 1), mirror=False, transp=False)
+    floor = dict(kind="sphere", O=(0, -1000, 0), R=990, albedo=(1, 1, 1), mirror=False, transp=False)
+    t = ob.TrueRefScene([light, floor, dict(kind="mesh", obj_path=obj, texture_paths=[jpg], ops=ops, albedo=(0, 0, 1), mirror=False, transp=False)], 6e9, (-10, 50, 40), build_bvh=False)
+    v, n, uv, ix, _ = t.mesh_arrays(2)
+    tex = t.mesh_texture(2, 0)
+    assert len(ix) == 54320 and tex.shape == (1024, 1024, 3)
+    t.build_bvh(2)
+    o = ob.OracleScene([light, floor, dict(kind="mesh", verts=v, normals=n, uvs=uv, idx=ix, textures=[tex], albedo=(0, 0, 1), mirror=False, transp=False)], 6e9, (-10, 50, 40))
+    W = 64
+    cam = rta.make_camera((5, -6, 20), 60.0, 0.0, 0.0, W)
+    rays, _ = ob.primary_rays(cam, W, W)
+    a, b = o.intersect_rays(rays), t.intersect_rays(rays)
+    assert (b["tri"] >= 0).sum() > 100
+    _same_hits(a, b)
+    boxes_t, dfl_t = t.bvh_dump(2)
+    info = o.bvh_info(2, len(ix))
+    assert info["n_nodes"] == len(boxes_t)
+    boxes_o, dfl_o = o.bvh_dump(2, len(boxes_t))
+    assert np.array_equal(boxes_o, boxes_t) and np.array_equal(dfl_o, dfl_t)
+    ijk = np.array([(i, j, 0) for i in range(0, W, 2) for j in range(0, W, 2)], np.int32)
+    p = rta.make_params(W, W, 1)
+    assert np.array_equal(o.sample_radiance(cam, p, ijk), t.sample_radiance(cam, p, ijk), equal_nan=True)
+
+
+def test_injected_stream_is_the_oracle_stream(ob):
+    """one engine value per uniform(engine) call, and (draw >> 11) * 2^-53 exactly"""
+    import ctypes as C
+    before = ob.trf.trf_draws()
+    objs = [dict(kind="sphere", O=(-10, 50, 40), R=5, albedo=(1, 1, 1), mirror=False, transp=False),
+            dict(kind="sphere", O=(0, -1000, 0), R=990, albedo=(1, 1, 1), mirror=False, transp=False)]
+    import importlib
+    rta = importlib.import_module("ray-tracing_amd")
+    t = ob.TrueRefScene(objs, 6e9, (-10, 50, 40))
+    cam = rta.make_camera(W=16)
+    t.sample_radiance(cam, rta.make_params(16, 16, 1), np.array([[12, 8, 0]], np.int32))
+    used = ob.trf.trf_draws() - before
+    assert used >= 4 and (used - 4) % 4 == 0  # 4 camera draws, then 4 per diffuse vertex (floor hits only)
