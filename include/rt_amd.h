@@ -216,6 +216,9 @@ int rt_sync(rt_ctx *ctx);
 /* Zero / read back the context's own accumulator (W*H*3 doubles). */
 int rt_accum_clear(rt_ctx *ctx, int32_t W, int32_t H);
 int rt_accum_download(rt_ctx *ctx, double *host_out, int64_t n_doubles);
+/* Load the context's own accumulator from host memory (resume an interrupted render: the accumulator is a
+ * plain sum of samples). rt_accum_clear(W, H) must have sized it. */
+int rt_accum_upload(rt_ctx *ctx, const double *host_in, int64_t n_doubles);
 /* Device address of the context's own accumulator (NULL before rt_accum_clear). */
 double *rt_accum_device_ptr(rt_ctx *ctx);
 

@@ -1,5 +1,9 @@
 """MI355X (gfx950) path tracer: Python binding of the C ABI in include/rt_amd.h.
 
+NOTE for processes that also use PyTorch: import torch BEFORE this package. torch ships its own copy of
+the HIP runtime under the same soname; whichever is loaded first is shared by both, and loading this
+library first makes torch load a second runtime whose device pointers the first one does not know.
+
 The compute path is the HIP library ``csrc/librt_amd.so`` (hand-written
 kernels + C ABI + C++ host classes). This module only loads it with ctypes and
 mirrors the reference's scene surface (Sphere / TriangleMesh / Scene and the
@@ -46,7 +50,7 @@ class rt_counters(C.Structure):
 
 # every symbol include/rt_amd.h and include/rt_amd_host.h declare
 RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_render", "rt_sync", "rt_accum_clear",
-              "rt_accum_download", "rt_accum_device_ptr", "rt_resolve", "rt_intersect_rays", "rt_sample_radiance",
+              "rt_accum_download", "rt_accum_upload", "rt_accum_device_ptr", "rt_resolve", "rt_intersect_rays", "rt_sample_radiance",
               "rt_get_counters", "rt_reset_counters", "rt_last_render_ms", "rt_stream", "rt_version"]
 RTH_SYMBOLS = ["rth_last_error", "rth_mesh_create", "rth_mesh_destroy", "rth_mesh_read_obj", "rth_mesh_load_texture",
                "rth_mesh_add_texture", "rth_mesh_set_raw", "rth_mesh_op", "rth_mesh_build_bvh", "rth_mesh_sizes",
@@ -71,6 +75,7 @@ _sig("rt_render", C.c_int, _vp, C.POINTER(rt_camera), C.POINTER(rt_params), _vp)
 _sig("rt_sync", C.c_int, _vp)
 _sig("rt_accum_clear", C.c_int, _vp, _i32, _i32)
 _sig("rt_accum_download", C.c_int, _vp, _vp, _i64)
+_sig("rt_accum_upload", C.c_int, _vp, _vp, _i64)
 _sig("rt_accum_device_ptr", _vp, _vp)
 _sig("rt_resolve", C.c_int, _vp, _vp, _i32, _i32, _dbl, _vp)
 _sig("rt_intersect_rays", C.c_int, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp)
@@ -320,6 +325,10 @@ class Renderer:
         out = np.empty((H, W, 3), np.float64)
         self._check(lib.rt_accum_download(self._h, _ptr(out), out.size))
         return out
+
+    def accum_upload(self, acc):
+        acc = np.ascontiguousarray(acc, np.float64)
+        self._check(lib.rt_accum_upload(self._h, _ptr(acc), acc.size))
 
     def accum_device_ptr(self):
         return lib.rt_accum_device_ptr(self._h)

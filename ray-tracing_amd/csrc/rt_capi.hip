@@ -678,6 +678,15 @@ int rt_accum_download(rt_ctx *c, double *host_out, int64_t n) {
     return check_overflow(c);
 }
 
+int rt_accum_upload(rt_ctx *c, const double *host_in, int64_t n) {
+    if (!c || !host_in) return RT_E_INVALID;
+    if (!c->accum || n != (int64_t)c->accW * c->accH * 3) return fail(c, RT_E_INVALID, "rt_accum_upload: size mismatch");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->accum, host_in, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
 int rt_resolve(rt_ctx *c, const double *accum, int32_t W, int32_t H, double spp_total, uint8_t *rgb8_host) {
     if (!c || !rgb8_host) return RT_E_INVALID;
     if (W <= 0 || H <= 0) return fail(c, RT_E_INVALID, "bad size");
