@@ -26,19 +26,27 @@ using namespace rtd;
 /* LDS of the wave; sphere lists of up to RT_LDS_SPHERES_MAX entries are staged behind the node stack
  * (every ray tests every sphere: raytracer.cpp:934-938), longer lists are read from global memory
  * with wave-uniform addresses. */
-__device__ __forceinline__ WaveLDS *wave_setup(const DScene &sc, unsigned char *lds_raw, const rt_sphere **sph) {
+__device__ __forceinline__ WaveLDS *wave_setup(const DScene &sc, unsigned char *lds_raw, const rt_sphere **sph, const RootRec **roots) {
     WaveLDS *w = reinterpret_cast<WaveLDS *>(lds_raw);
-    if (sc.n_spheres > RT_LDS_SPHERES_MAX) {
-        *sph = sc.spheres;
-        return w;
+    unsigned char *p = const_cast<unsigned char *>(reinterpret_cast<const unsigned char *>(lds_spheres(w, sc.node_cap)));
+    *sph = sc.spheres;
+    *roots = sc.roots;
+    if (sc.n_spheres <= RT_LDS_SPHERES_MAX) {
+        const int n16 = sc.n_spheres * (int)(sizeof(rt_sphere) / 16);
+        const uint4 *src = reinterpret_cast<const uint4 *>(sc.spheres);
+        uint4 *d16 = reinterpret_cast<uint4 *>(p);
+        for (int q = threadIdx.x; q < n16; q += RT_BLOCK) d16[q] = src[q];
+        *sph = reinterpret_cast<const rt_sphere *>(p);
+        p += (size_t)sc.n_spheres * sizeof(rt_sphere);
     }
-    rt_sphere *dst = const_cast<rt_sphere *>(lds_spheres(w, sc.node_cap));
-    const int n16 = sc.n_spheres * (int)(sizeof(rt_sphere) / 16);
-    const uint4 *src = reinterpret_cast<const uint4 *>(sc.spheres);
-    uint4 *d16 = reinterpret_cast<uint4 *>(dst);
-    for (int q = threadIdx.x; q < n16; q += RT_BLOCK) d16[q] = src[q];
+    if (sc.n_meshes <= RT_LDS_ROOTS_MAX) {
+        const int n16 = sc.n_meshes * (int)(sizeof(RootRec) / 16);
+        const uint4 *src = reinterpret_cast<const uint4 *>(sc.roots);
+        uint4 *d16 = reinterpret_cast<uint4 *>(p);
+        for (int q = threadIdx.x; q < n16; q += RT_BLOCK) d16[q] = src[q];
+        *roots = reinterpret_cast<const RootRec *>(p);
+    }
     wave_sync();
-    *sph = dst;
     return w;
 }
 
@@ -59,11 +67,12 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_render_kernel(DScene sc, RenderAr
                                                              rt_counters *counters) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const rt_sphere *sph;
-    WaveLDS *w = wave_setup(sc, lds_raw, &sph);
+    const RootRec *roots;
+    WaveLDS *w = wave_setup(sc, lds_raw, &sph, &roots);
     int i, j;
     const bool live = lane_pixel(ra, i, j);
     Cnt cnt = {};
-    V3 a = trace_pixel<CNT>(sc, w, sph, ra, live, i, j, k0, nk, cnt);
+    V3 a = trace_pixel<CNT>(sc, w, sph, roots, ra, live, i, j, k0, nk, cnt);
     if (live) {
         double *px = accum + ((int64_t)i * ra.p.W + j) * 3;
         /* one lane owns the pixel for the whole launch and launches on a stream are ordered */
@@ -78,12 +87,13 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_render_kernel(DScene sc, RenderAr
 __global__ void __launch_bounds__(RT_BLOCK) rt_sample_kernel(DScene sc, RenderArgs ra, const int32_t *ijk, int64_t n, double *out) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const rt_sphere *sph;
-    WaveLDS *w = wave_setup(sc, lds_raw, &sph);
+    const RootRec *roots;
+    WaveLDS *w = wave_setup(sc, lds_raw, &sph, &roots);
     const int64_t q = (int64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
     const bool live = q < n;
     Cnt cnt = {};
     const int i = live ? ijk[3 * q] : 0, j = live ? ijk[3 * q + 1] : 0, k = live ? ijk[3 * q + 2] : 0;
-    V3 a = trace_pixel<false>(sc, w, sph, ra, live, i, j, k, 1, cnt);
+    V3 a = trace_pixel<false>(sc, w, sph, roots, ra, live, i, j, k, 1, cnt);
     if (live) {
         out[3 * q] = a.x;
         out[3 * q + 1] = a.y;
@@ -96,14 +106,15 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_intersect_kernel(DScene sc, const
                                                                 int32_t *tri_id, double *t, double *PN, double *albedo) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const rt_sphere *sph;
-    WaveLDS *w = wave_setup(sc, lds_raw, &sph);
+    const RootRec *roots;
+    WaveLDS *w = wave_setup(sc, lds_raw, &sph, &roots);
     const int64_t q = (int64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
     const bool live = q < n;
     V3 C = mk(0, 0, 0), u = mk(0, 0, 1);
     if (live) { C = ld3(rays + 6 * q); u = ld3(rays + 6 * q + 3); }
     HitRec h;
     Cnt cnt = {};
-    bool ok = scene_closest_wave<false>(sc, w, sph, live, C, u, 1E10, false, prune != 0, h, cnt);
+    bool ok = scene_closest_wave<false>(sc, w, sph, roots, live, C, u, 1E10, false, prune != 0, h, cnt);
     if (!live) return;
     obj_id[q] = ok ? h.obj : -1;
     tri_id[q] = (ok && h.mesh >= 0) ? sc.tris[h.prim].orig_id : -1;
@@ -196,7 +207,8 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_wf_traverse(DScene sc, WfBuf b, i
     const int64_t base = (int64_t)blockIdx.x * RT_BLOCK;
     if (base >= count) return;
     const rt_sphere *sph;
-    WaveLDS *w = wave_setup(sc, lds_raw, &sph);
+    const RootRec *roots;
+    WaveLDS *w = wave_setup(sc, lds_raw, &sph, &roots);
     const int64_t idx = base + threadIdx.x;
     const bool live = idx < count;
     int64_t s = 0;
@@ -212,7 +224,7 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_wf_traverse(DScene sc, WfBuf b, i
     }
     HitRec h;
     Cnt cnt = {};
-    (void)scene_closest_wave<false>(sc, w, sph, live, C, u, tmax, shadow, prune != 0, h, cnt);
+    (void)scene_closest_wave<false>(sc, w, sph, roots, live, C, u, tmax, shadow, prune != 0, h, cnt);
     if (live) {
         b.hd[s] = h.t; b.hd[b.n + s] = h.beta; b.hd[2 * b.n + s] = h.gamma;
         b.hi[s] = h.obj; b.hi[b.n + s] = h.prim; b.hi[2 * b.n + s] = h.mesh;
@@ -484,6 +496,17 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
     if ((rc = upload_array(c, s->attrs, (size_t)s->n_tris, &d.attrs))) return rc;
     if ((rc = upload_array(c, s->tex, (size_t)s->n_tex, &d.tex))) return rc;
     if ((rc = upload_array(c, s->texels, (size_t)s->texel_bytes, &d.texels))) return rc;
+    {
+        std::vector<RootRec> rr((size_t)s->n_meshes);
+        for (int mi = 0; mi < s->n_meshes; mi++) {
+            memset(&rr[mi], 0, sizeof(RootRec));
+            for (int k = 0; k < 6; k++) rr[mi].box[k] = s->meshes[mi].root_box[k];
+            rr[mi].root = s->meshes[mi].root;
+            rr[mi].root_count = s->meshes[mi].root_count;
+        }
+        if ((rc = upload_array(c, rr.data(), rr.size(), &d.roots))) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream)); /* rr goes out of scope */
+    }
     double lut[256];
     if (s->srgb_lut) memcpy(lut, s->srgb_lut, sizeof lut);
     else for (int i = 0; i < 256; i++) lut[i] = pow(i / 255., 2.2); /* raytracer.cpp:713-715 */
@@ -501,7 +524,8 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
     d.node_cap = RT_NODE_SOFT + max_depth + 2;
     d.overflow = c->d_overflow;
     c->sc = d;
-    c->lds_bytes = sizeof(WaveLDS) + (size_t)d.node_cap * 8 + 16 + ((s->n_spheres <= RT_LDS_SPHERES_MAX) ? (size_t)s->n_spheres * sizeof(rt_sphere) : 0);
+    c->lds_bytes = sizeof(WaveLDS) + (size_t)d.node_cap * 8 + 16 + ((s->n_spheres <= RT_LDS_SPHERES_MAX) ? (size_t)s->n_spheres * sizeof(rt_sphere) : 0) +
+                   ((s->n_meshes <= RT_LDS_ROOTS_MAX) ? (size_t)s->n_meshes * sizeof(RootRec) : 0);
     if (c->lds_bytes > 64 * 1024) return fail(c, RT_E_INVALID, "rt_upload_scene: per-wave LDS of %zu bytes exceeds 64 KiB", c->lds_bytes);
     c->have_scene = true;
     return RT_OK;

@@ -33,6 +33,7 @@ namespace rtd {
 
 #define RT_WAVE 64
 #define RT_LDS_SPHERES_MAX 64     /* sphere lists up to this size are staged in LDS */
+#define RT_LDS_ROOTS_MAX 32       /* mesh root records (box + root) up to this many are staged in LDS */
 #define RT_MESH_CHUNK 4           /* meshes whose roots enter the pool together */
 #define RT_NODE_SOFT 512          /* node-item stack height up to which 64 items are popped per step */
 #define RT_LEAF_CAP 256           /* leaf-item stack entries */
@@ -40,8 +41,16 @@ namespace rtd {
 #define RT_NODE_BITS 26           /* node index bits in a node item (the ray lane takes the top 6) */
 #define RT_MAX_DEPTH 60
 
+/* what the root phase needs of a mesh: the root box (raytracer.cpp:644) and where the tree starts */
+struct RootRec {
+    double box[6];
+    int32_t root, root_count;
+    int32_t pad[2];
+};
+
 struct DScene {
     const rt_sphere *spheres;
+    const RootRec *roots;
     const rt_mesh *meshes;
     const rt_bvh_node *nodes;
     const rt_tri *tris;
@@ -248,7 +257,7 @@ __device__ __forceinline__ void wave_sync() {
  * anyhit = it only tests "hit && t < tmax" (the shadow test, raytracer.cpp:1073), so hits at or beyond
  * tmax need not be found and the first one below it settles the ray. */
 template <bool CNT>
-__device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w, const rt_sphere *sph, bool active, V3 C, V3 u,
+__device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w, const rt_sphere *sph, const RootRec *roots, bool active, V3 C, V3 u,
                                                    double tmax, bool anyhit, bool prune, HitRec &h, Cnt &cnt) {
     const int lane = lane_id();
     h.t = 1E10;
@@ -307,13 +316,13 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
          * Roots are fed in groups small enough for the stacks (at most RT_MESH_CHUNK meshes). */
         const int root_budget = RT_WAVE * RT_MESH_CHUNK;
         while (mi < sc.n_meshes && n_nodes + RT_WAVE <= root_budget && n_leaves + 4 * RT_WAVE <= RT_LEAF_CAP) {
-            const rt_mesh &m = sc.meshes[mi];
+            const RootRec &m = roots[mi];
             mi++;
             bool pass = false;
             double tn = 0;
             if (active) {
                 if (CNT) cnt.box_tests++;
-                pass = box_hit(ldbox(m.root_box), C, u, iu, tn);
+                pass = box_hit(ldbox(m.box), C, u, iu, tn);
                 if (CNT && pass) cnt.mesh_calls++;
                 pass = pass && !(tn > my_thr);
             }
@@ -745,7 +754,7 @@ __device__ __forceinline__ void path_advance(const DScene &sc, const rt_sphere *
  * order (the k loop of raytracer.cpp:1464-1486). Called by all 64 lanes of the wave; lanes with
  * live == false only help in the pool. */
 template <bool CNT>
-__device__ __forceinline__ V3 trace_pixel(const DScene &sc, WaveLDS *w, const rt_sphere *sph, const RenderArgs &ra, bool live, int i,
+__device__ __forceinline__ V3 trace_pixel(const DScene &sc, WaveLDS *w, const rt_sphere *sph, const RootRec *roots, const RenderArgs &ra, bool live, int i,
                                           int j, int k0, int nk, Cnt &cnt) {
     Path q;
     path_begin(q, k0, live);
@@ -757,7 +766,7 @@ __device__ __forceinline__ V3 trace_pixel(const DScene &sc, WaveLDS *w, const rt
         if (__ballot(!q.finished) == 0ull) break;
         if (CNT) cnt.cyc_fresh += RT_STAMP() - sp0;
         HitRec h;
-        bool inter = scene_closest_wave<CNT>(sc, w, sph, !q.finished, q.rC, q.ru, q.shadow ? q.sh_limit : 1E10, q.shadow,
+        bool inter = scene_closest_wave<CNT>(sc, w, sph, roots, !q.finished, q.rC, q.ru, q.shadow ? q.sh_limit : 1E10, q.shadow,
                                              !(ra.p.flags & RT_F_NO_PRUNE), h, cnt);
         if (CNT) sp0 = RT_STAMP();
         if (!q.finished) path_advance<CNT>(sc, sph, ra, q, inter, h, cnt);

@@ -202,3 +202,34 @@ def test_errors(gpu, rta, scenes):
         gpu.render(cam, rta.make_params(32, 32, 1, rect=(0, 0, 64, 64)))
     with pytest.raises(rta.RTError):
         gpu.render(cam, rta.make_params(32, 32, 1))  # accumulator not allocated for 32x32
+
+
+def test_cpp_host_program_matches_python_path(gpu, rta, scenes, tmp_path):
+    """examples/render_room.cpp = the reference's main() against rt_host.hpp (readOBJ, PPM loadTexture, transforms,
+    buildBVH, rt::render). Same bytes as the same scene built through the Python binding."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "render_room")
+    assert os.path.exists(exe), "build() makes it"
+    v, n, uv, ix = scenes.blob_mesh(12, size=(0.3, 0.6, 0.72), offset=(0, 0, 0.72), seed=5)
+    obj, tex, out = str(tmp_path / "m.obj"), str(tmp_path / "t.ppm"), str(tmp_path / "o.ppm")
+    scenes.write_obj(obj, v, n, uv, ix)
+    t = scenes.procedural_texture(64, 3)
+    with open(tex, "wb") as f:
+        f.write(b"P6\n# made by the test\n64 64\n255\n" + t.tobytes())
+    W, spp = 96, 3
+    r = subprocess.run([exe, out, str(W), str(spp), obj, tex], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    data = open(out, "rb").read()
+    img = np.frombuffer(data[-W * W * 3:], np.uint8).reshape(W, W, 3)
+    s, cam, flags = scenes.sphere_room(W)
+    m = rta.TriangleMesh((0, 0, 1)).readOBJ(obj).loadTexture(tex)
+    m.zoom(4).rotate(1, 2).rotate(0, 2).translate(1, -10).rotateAroundAxe(1, -30).translate(0, 5).translate(2, 25).buildBVH()
+    s.add(m)
+    gpu.upload(s)
+    gpu.accum_clear(W, W)
+    gpu.render(cam, rta.make_params(W, W, spp))
+    assert np.array_equal(gpu.resolve(W, W, spp), img)
+    r = subprocess.run([exe, out, "32", "1", "/nonexistent.obj"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "cannot open" in r.stderr
