@@ -50,36 +50,15 @@ __device__ __forceinline__ WaveLDS *wave_setup(const DScene &sc, unsigned char *
     return w;
 }
 
-/* pixel of a lane: 8x8 pixel tiles per wave so the camera rays of a wave stay together */
-__device__ __forceinline__ bool lane_pixel(const RenderArgs &ra, int &i, int &j) {
-    const int rw = ra.j1 - ra.j0, rh = ra.i1 - ra.i0;
-    const int tiles_x = (rw + 7) >> 3;
-    const int tile = blockIdx.x, lane = threadIdx.x & 63;
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    j = ra.j0 + tx * 8 + (lane & 7);
-    i = ra.i0 + ty * 8 + (lane >> 3);
-    (void)rh;
-    return (j < ra.j1) && (i < ra.i1);
-}
-
 template <bool CNT>
 __global__ void __launch_bounds__(RT_BLOCK) rt_render_kernel(DScene sc, RenderArgs ra, int k0, int nk, double *accum,
-                                                             rt_counters *counters) {
+                                                             rt_counters *counters, int *next_slot, int n_slots) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const rt_sphere *sph;
     const RootRec *roots;
     WaveLDS *w = wave_setup(sc, lds_raw, &sph, &roots);
-    int i, j;
-    const bool live = lane_pixel(ra, i, j);
     Cnt cnt = {};
-    V3 a = trace_pixel<CNT>(sc, w, sph, roots, ra, live, i, j, k0, nk, cnt);
-    if (live) {
-        double *px = accum + ((int64_t)i * ra.p.W + j) * 3;
-        /* one lane owns the pixel for the whole launch and launches on a stream are ordered */
-        px[0] = px[0] + a.x;
-        px[1] = px[1] + a.y;
-        px[2] = px[2] + a.z;
-    }
+    render_persistent<CNT>(sc, w, sph, roots, ra, k0, nk, accum, next_slot, n_slots, cnt);
     if (CNT) flush_counters(cnt, counters);
 }
 
@@ -175,17 +154,6 @@ __device__ __forceinline__ void wf_load(const WfBuf &b, int64_t s, Path &q) {
     const uint32_t f = b.u[4 * b.n + s];
     q.rebond = (int32_t)(f & 0xFFFFu); q.lastDiffuse = f & (1u << 16); q.shadow = f & (1u << 17); q.fresh = f & (1u << 18);
     q.finished = f & (1u << 19);
-}
-
-/* slot -> pixel: 8x8 tiles, as lane_pixel */
-__device__ __forceinline__ bool slot_pixel(const RenderArgs &ra, int64_t slot, int &i, int &j) {
-    const int rw = ra.j1 - ra.j0;
-    const int tiles_x = (rw + 7) >> 3;
-    const int tile = (int)(slot >> 6), lane = (int)(slot & 63);
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    j = ra.j0 + tx * 8 + (lane & 7);
-    i = ra.i0 + ty * 8 + (lane >> 3);
-    return (j < ra.j1) && (i < ra.i1);
 }
 
 __global__ void __launch_bounds__(256) rt_wf_init(WfBuf b, RenderArgs ra, int k0) {
@@ -318,6 +286,8 @@ struct rt_ctx {
     int accW = 0, accH = 0;
     rt_counters *d_counters = nullptr;
     int *d_overflow = nullptr;
+    int *d_next_slot = nullptr;
+    int n_cus = 256;
     bool probe_prune = true;
     /* wavefront state */
     WfBuf wf{};
@@ -391,10 +361,15 @@ int rt_create(int device, rt_ctx **out) {
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
         (e = hipMalloc((void **)&c->d_counters, RT_COUNTER_WORDS * 8)) != hipSuccess ||
         (e = hipMemset(c->d_counters, 0, RT_COUNTER_WORDS * 8)) != hipSuccess ||
-        (e = hipMalloc((void **)&c->d_overflow, sizeof(int))) != hipSuccess || (e = hipMemset(c->d_overflow, 0, sizeof(int))) != hipSuccess) {
+        (e = hipMalloc((void **)&c->d_overflow, sizeof(int))) != hipSuccess || (e = hipMemset(c->d_overflow, 0, sizeof(int))) != hipSuccess ||
+        (e = hipMalloc((void **)&c->d_next_slot, sizeof(int))) != hipSuccess) {
         fail(nullptr, RT_E_DEVICE, "rt_create: %s", hipGetErrorString(e));
         delete c;
         return RT_E_DEVICE;
+    }
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
     }
     *out = c;
     return RT_OK;
@@ -408,6 +383,7 @@ void rt_destroy(rt_ctx *c) {
     if (c->accum) (void)hipFree(c->accum);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_overflow) (void)hipFree(c->d_overflow);
+    if (c->d_next_slot) (void)hipFree(c->d_next_slot);
     if (c->wf_alloc) (void)hipFree(c->wf_alloc);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -633,19 +609,23 @@ int rt_render(rt_ctx *c, const rt_camera *cam, const rt_params *p, double *accum
     HIPCHK(c, hipSetDevice(c->device));
     const int rw = ra.j1 - ra.j0, rh = ra.i1 - ra.i0;
     const int64_t tiles = (int64_t)((rw + 7) / 8) * ((rh + 7) / 8);
-    if (tiles > 0x7fffffffLL) return fail(c, RT_E_INVALID, "too many tiles");
+    if (tiles * RT_WAVE > 0x7fffffffLL) return fail(c, RT_E_INVALID, "too many tiles");
     const unsigned grid = (unsigned)tiles;
     c->last_launches = 0;
     c->timed = false;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if ((p->flags & RT_F_COUNTERS) || !(p->flags & RT_F_WAVEFRONT)) {
         /* single persistent kernel (default, and the only counted variant) */
+        /* persistent waves: as many as stay resident (8 per CU at this register use), each pulling 64-pixel tiles */
+        const int n_slots = (int)(tiles * RT_WAVE);
+        const unsigned pgrid = grid < (unsigned)(c->n_cus * 8) ? grid : (unsigned)(c->n_cus * 8);
         for (int k = 0; k < p->spp; k += kSppPerLaunch) {
             const int nk = (p->spp - k < kSppPerLaunch) ? (p->spp - k) : kSppPerLaunch;
+            HIPCHK(c, hipMemsetAsync(c->d_next_slot, 0, sizeof(int), c->stream));
             if (p->flags & RT_F_COUNTERS)
-                hipLaunchKernelGGL(rt_render_kernel<true>, dim3(grid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, accum, c->d_counters);
+                hipLaunchKernelGGL(rt_render_kernel<true>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, accum, c->d_counters, c->d_next_slot, n_slots);
             else
-                hipLaunchKernelGGL(rt_render_kernel<false>, dim3(grid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, accum, c->d_counters);
+                hipLaunchKernelGGL(rt_render_kernel<false>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, accum, c->d_counters, c->d_next_slot, n_slots);
             HIPCHK(c, hipGetLastError());
             c->last_launches++;
         }

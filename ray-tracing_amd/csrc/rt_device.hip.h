@@ -775,6 +775,79 @@ __device__ __forceinline__ V3 trace_pixel(const DScene &sc, WaveLDS *w, const rt
     return q.acc;
 }
 
+/* slot -> pixel of the render rectangle: slots run over 8x8 pixel tiles (64 consecutive slots = one tile) so the
+ * camera rays a wave starts together stay together */
+__device__ __forceinline__ bool slot_pixel(const RenderArgs &ra, int64_t slot, int &i, int &j) {
+    const int rw = ra.j1 - ra.j0;
+    const int tiles_x = (rw + 7) >> 3;
+    const int tile = (int)(slot >> 6), ln = (int)(slot & 63);
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    j = ra.j0 + tx * 8 + (ln & 7);
+    i = ra.i0 + ty * 8 + (ln >> 3);
+    return (j < ra.j1) && (i < ra.i1);
+}
+
+/* The render loop of a persistent wave. Lanes take pixels ("slots") from a global counter, one 64-slot tile
+ * per request; a lane keeps its pixel for all nk samples (added in order, raytracer.cpp:1464-1486), writes the
+ * sum and takes the next free slot. Because lanes re-fill independently, the wave's pool stays full until the
+ * whole frame runs out of pixels, instead of idling while the longest of 64 fixed pixels finishes. */
+template <bool CNT>
+__device__ __forceinline__ void render_persistent(const DScene &sc, WaveLDS *w, const rt_sphere *sph, const RootRec *roots,
+                                                  const RenderArgs &ra, int k0, int nk, double *accum, int *next_slot, int n_slots,
+                                                  Cnt &cnt) {
+    Path q;
+    path_begin(q, k0, false); /* finished: no pixel yet */
+    const int kend = k0 + nk;
+    bool have = false, exhausted = false;
+    int i = 0, j = 0;
+    int cur = 0, end = 0; /* wave-uniform: the part of the last tile request not handed out yet */
+    uint64_t sp0 = 0;
+    while (true) {
+        if (CNT) sp0 = RT_STAMP();
+        if (have && q.finished) { /* all samples of this lane's pixel are in q.acc */
+            double *px = accum + ((int64_t)i * ra.p.W + j) * 3;
+            px[0] = px[0] + q.acc.x;
+            px[1] = px[1] + q.acc.y;
+            px[2] = px[2] + q.acc.z;
+            have = false;
+        }
+        const unsigned long long need = __ballot(!have && !exhausted);
+        if (need) {
+            if (cur == end) { /* one atomic per tile */
+                int base = 0;
+                if (lane_id() == 0) base = atomicAdd(next_slot, RT_WAVE);
+                cur = uni(base);
+                end = cur + RT_WAVE < n_slots ? cur + RT_WAVE : n_slots;
+                if (cur >= n_slots) { cur = end = n_slots; }
+            }
+            if (!have && !exhausted) {
+                const int mine = cur + rank_in(need);
+                if (cur >= n_slots) {
+                    exhausted = true;
+                } else if (mine < end) {
+                    const bool live = slot_pixel(ra, mine, i, j);
+                    path_begin(q, k0, live);
+                    have = live; /* a slot outside the rectangle is skipped */
+                }
+            }
+            const int taken = __popcll(need);
+            cur = (cur + taken < end) ? cur + taken : end;
+        }
+        path_fresh<CNT>(ra, q, i, j, kend, cnt);
+        if (__ballot(!q.finished) == 0ull) {
+            if (__ballot(!exhausted || have) == 0ull) break;
+            continue; /* nothing to trace this round: only bookkeeping (pixels ended or were just assigned) */
+        }
+        if (CNT) cnt.cyc_fresh += RT_STAMP() - sp0;
+        HitRec h;
+        bool inter = scene_closest_wave<CNT>(sc, w, sph, roots, !q.finished, q.rC, q.ru, q.shadow ? q.sh_limit : 1E10, q.shadow,
+                                             !(ra.p.flags & RT_F_NO_PRUNE), h, cnt);
+        if (CNT) sp0 = RT_STAMP();
+        if (!q.finished) path_advance<CNT>(sc, sph, ra, q, inter, h, cnt);
+        if (CNT) cnt.cyc_shade += RT_STAMP() - sp0;
+    }
+}
+
 /* wave-reduce a counter set and add it to global memory with one atomic per field per wave */
 __device__ __forceinline__ void flush_counters(const Cnt &c, rt_counters *out) {
     uint64_t v[8] = {c.paths, c.rays, c.box_tests, c.nodes, c.tris, c.mesh_calls, c.diffuse, c.specular};
