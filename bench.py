@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--spp-step", type=int, default=16, help="samples per pixel per rank per step")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=2)
+    ap.add_argument("--cpu-spp", type=int, default=12, help="samples per pixel of the CPU baseline's bounded sample (12 spp = about 15 s on 16 cores)")
     ap.add_argument("--out-png", default="")
     ap.add_argument("--mode", default="default", choices=["default", "wavefront"], help="A/B switch: two-kernel wavefront render loop instead of the single persistent kernel")
     args = ap.parse_args()

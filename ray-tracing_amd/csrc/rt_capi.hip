@@ -339,7 +339,8 @@ static int check_overflow(rt_ctx *c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (flag) {
         (void)hipMemsetAsync(c->d_overflow, 0, sizeof(int), c->stream);
-        return fail(c, RT_E_DEVICE, "traversal pool overflow: results of the last launch are incomplete");
+        return fail(c, RT_E_DEVICE, "traversal pool %s: results of the last launch are incomplete",
+                    (flag & 2) ? "produced an index outside the scene arrays" : "overflow");
     }
     return RT_OK;
 }
@@ -499,6 +500,8 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
     HIPCHK(c, hipStreamSynchronize(c->stream)); /* host arrays may be released after return */
     d.node_cap = RT_NODE_SOFT + max_depth + 2;
     d.overflow = c->d_overflow;
+    d.n_tris_total = (uint32_t)s->n_tris;
+    d.n_nodes_total = (uint32_t)s->n_nodes;
     c->sc = d;
     c->lds_bytes = sizeof(WaveLDS) + (size_t)d.node_cap * 8 + 16 + ((s->n_spheres <= RT_LDS_SPHERES_MAX) ? (size_t)s->n_spheres * sizeof(rt_sphere) : 0) +
                    ((s->n_meshes <= RT_LDS_ROOTS_MAX) ? (size_t)s->n_meshes * sizeof(RootRec) : 0);

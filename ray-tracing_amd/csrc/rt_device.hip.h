@@ -61,7 +61,8 @@ struct DScene {
     int32_t n_spheres, n_meshes;
     int32_t node_cap; /* node-item stack entries: RT_NODE_SOFT + max_depth + 2 */
     int32_t pad;
-    int *overflow;    /* set to 1 if a node push would have passed node_cap */
+    uint32_t n_tris_total, n_nodes_total; /* array lengths: every index taken from the pool is checked against them */
+    int *overflow;    /* bit 0: a push would have passed a stack's capacity; bit 1: an index outside the arrays */
     double I;
     double L[3];
     double lightO[3];
@@ -385,7 +386,9 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
                 const int k = take;
                 bool acc = false;
                 double beta, gamma, lt = 0;
-                if (have) {
+                if (have && tri >= sc.n_tris_total) { /* never fetch outside the arrays */
+                    atomicOr(sc.overflow, 2);
+                } else if (have) {
                     if (CNT) cnt.tris++;
                     V3 rc = mk(w->ray[0][rl], w->ray[1][rl], w->ray[2][rl]);
                     V3 ru = mk(w->ray[3][rl], w->ray[4][rl], w->ray[5][rl]);
@@ -434,6 +437,10 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
                 if (have) {
                     thr = w->thr[rl];
                     have = !((double)__uint_as_float(it.y) > thr); /* fallen behind the threshold since it was pushed */
+                    if ((it.x & ((1u << RT_NODE_BITS) - 1u)) >= sc.n_nodes_total) { /* never fetch outside the arrays */
+                        have = false;
+                        atomicOr(sc.overflow, 2);
+                    }
                 }
                 if (have) {
                     /* the whole 128-byte record in one batch of loads, before either box is tested */
