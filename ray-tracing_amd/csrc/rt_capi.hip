@@ -18,6 +18,10 @@ using namespace rtd;
 
 #define RT_COUNTER_WORDS 20 /* rt_counters (8 words) + 12 diagnostic words of rt_device.hip.h */
 #define RT_BLOCK 64 /* one workgroup = one wave: the LDS pool of rt_device.hip.h is per wave */
+#ifndef RT_WAVES_PER_SIMD
+#define RT_WAVES_PER_SIMD 2 /* resident waves per SIMD the render kernel is compiled for (register budget 512 / this) */
+#endif
+#define RT_OCCUPANCY __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_SIMD, RT_WAVES_PER_SIMD)))
 
 /* ---------------------------------------------------------------------------------------------
  * kernels
@@ -51,7 +55,7 @@ __device__ __forceinline__ WaveLDS *wave_setup(const DScene &sc, unsigned char *
 }
 
 template <bool CNT>
-__global__ void __launch_bounds__(RT_BLOCK) rt_render_kernel(DScene sc, RenderArgs ra, int k0, int nk, double *accum,
+__global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_kernel(DScene sc, RenderArgs ra, int k0, int nk, double *accum,
                                                              rt_counters *counters, int *next_slot, int n_slots) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const rt_sphere *sph;
@@ -447,8 +451,19 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
                 if (g < 0 || g >= m.n_tex) return fail(c, RT_E_INVALID, "mesh %d: triangle %d has texture group %d but the mesh has %d textures", mi, k, g, m.n_tex);
             }
     }
+    /* largest |coordinate| of any box, per axis: scales the tolerance of the fast box test (rt_device.hip.h) */
+    double bmax[3] = {0, 0, 0};
+    auto widen = [&bmax](const double *box) {
+        for (int k = 0; k < 6; k++) {
+            const double a = fabs(box[k]);
+            if (!(a <= bmax[k % 3])) bmax[k % 3] = std::isfinite(a) && std::isfinite(bmax[k % 3]) ? a : HUGE_VAL;
+        }
+    };
+    for (int mi = 0; mi < s->n_meshes; mi++) widen(s->meshes[mi].root_box);
     for (int64_t k = 0; k < s->n_nodes; k++) {
         const rt_bvh_node &nd = s->nodes[k];
+        widen(nd.boxL);
+        widen(nd.boxR);
         const int32_t idx[2] = {nd.L, nd.R}, cnt[2] = {nd.nL, nd.nR};
         for (int q = 0; q < 2; q++) {
             if (cnt[q] < 0) return fail(c, RT_E_INVALID, "node %lld: negative leaf count", (long long)k);
@@ -500,6 +515,7 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
     HIPCHK(c, hipStreamSynchronize(c->stream)); /* host arrays may be released after return */
     d.node_cap = RT_NODE_SOFT + max_depth + 2;
     d.overflow = c->d_overflow;
+    for (int k = 0; k < 3; k++) d.bmax[k] = bmax[k];
     d.n_tris_total = (uint32_t)s->n_tris;
     d.n_nodes_total = (uint32_t)s->n_nodes;
     c->sc = d;
@@ -619,9 +635,9 @@ int rt_render(rt_ctx *c, const rt_camera *cam, const rt_params *p, double *accum
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if ((p->flags & RT_F_COUNTERS) || !(p->flags & RT_F_WAVEFRONT)) {
         /* single persistent kernel (default, and the only counted variant) */
-        /* persistent waves: as many as stay resident (8 per CU at this register use), each pulling 64-pixel tiles */
+        /* persistent waves: as many as stay resident (4 SIMDs x RT_WAVES_PER_SIMD per CU), each pulling 64-pixel tiles */
         const int n_slots = (int)(tiles * RT_WAVE);
-        const unsigned pgrid = grid < (unsigned)(c->n_cus * 8) ? grid : (unsigned)(c->n_cus * 8);
+        const unsigned pgrid = grid < (unsigned)(c->n_cus * 4 * RT_WAVES_PER_SIMD) ? grid : (unsigned)(c->n_cus * 4 * RT_WAVES_PER_SIMD);
         for (int k = 0; k < p->spp; k += kSppPerLaunch) {
             const int nk = (p->spp - k < kSppPerLaunch) ? (p->spp - k) : kSppPerLaunch;
             HIPCHK(c, hipMemsetAsync(c->d_next_slot, 0, sizeof(int), c->stream));

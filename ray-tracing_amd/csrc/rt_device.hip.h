@@ -17,11 +17,12 @@
  *     rays they belong to - test them, and push the children that were hit. Lane utilisation no
  *     longer depends on how many of the wave's rays reach a mesh or how deep each goes (a per-lane
  *     traversal ran at 6 % VALU lane utilisation on the battle scene).
- *   - The pool visits exactly the BVH records and triangles the reference visits (every node whose
- *     box test passes, no pruning by distance: raytracer.cpp:652-666), in a different order. The
- *     reference's result depends on order only through exact ties in t, where the first visited wins;
- *     triangles are laid out in that visiting order (see rt_tri in rt_amd.h), so the tie-break is
- *     "lowest position" and the result is order-independent.
+ *   - With RT_F_NO_PRUNE the pool visits exactly the BVH records and triangles the reference visits
+ *     (every node whose box test passes: raytracer.cpp:652-666), in a different order; by default it
+ *     also skips boxes that lie wholly behind the ray's current closest hit, which cannot change the
+ *     result. The reference's result depends on order only through exact ties in t, where the first
+ *     visited wins; triangles are laid out in that visiting order (see rt_tri in rt_amd.h), so the
+ *     tie-break is "lowest position" and the result is order-independent.
  */
 #pragma once
 #include <hip/hip_runtime.h>
@@ -34,8 +35,10 @@ namespace rtd {
 #define RT_WAVE 64
 #define RT_LDS_SPHERES_MAX 64     /* sphere lists up to this size are staged in LDS */
 #define RT_LDS_ROOTS_MAX 32       /* mesh root records (box + root) up to this many are staged in LDS */
-#define RT_MESH_CHUNK 4           /* meshes whose roots enter the pool together */
-#define RT_NODE_SOFT 512          /* node-item stack height up to which 64 items are popped per step */
+#define RT_FEED_BELOW 64          /* mesh roots are fed to the pool while fewer node items than this are pending */
+#ifndef RT_NODE_SOFT
+#define RT_NODE_SOFT 512
+#endif          /* node-item stack height up to which 64 items are popped per step */
 #define RT_LEAF_CAP 256           /* leaf-item stack entries */
 #define RT_LEAF_TRIGGER 24        /* pending leaf items that make the next pool step a triangle step */
 #define RT_NODE_BITS 26           /* node index bits in a node item (the ray lane takes the top 6) */
@@ -61,6 +64,7 @@ struct DScene {
     int32_t n_spheres, n_meshes;
     int32_t node_cap; /* node-item stack entries: RT_NODE_SOFT + max_depth + 2 */
     int32_t pad;
+    double bmax[3];   /* largest |coordinate| of any box of the scene, per axis (infinity if one is not finite) */
     uint32_t n_tris_total, n_nodes_total; /* array lengths: every index taken from the pool is checked against them */
     int *overflow;    /* bit 0: a push would have passed a stack's capacity; bit 1: an index outside the arrays */
     double I;
@@ -127,12 +131,12 @@ struct Box6 {
     double lx, ly, lz, hx, hy, hz;
 };
 __device__ __forceinline__ Box6 ldbox(const double *b) { return Box6{b[0], b[1], b[2], b[3], b[4], b[5]}; }
-__device__ __noinline__ bool box_hit_exact(Box6 b, V3 C, V3 u) {
-    double t1x = (b.lx - C.x) / u.x, t2x = (b.hx - C.x) / u.x;
+__device__ __noinline__ bool box_hit_exact(const double *b, double cx, double cy, double cz, double ux, double uy, double uz) {
+    double t1x = (b[0] - cx) / ux, t2x = (b[3] - cx) / ux;
     double txMin = smin(t1x, t2x), txMax = smax(t1x, t2x);
-    double t1y = (b.ly - C.y) / u.y, t2y = (b.hy - C.y) / u.y;
+    double t1y = (b[1] - cy) / uy, t2y = (b[4] - cy) / uy;
     double tyMin = smin(t1y, t2y), tyMax = smax(t1y, t2y);
-    double t1z = (b.lz - C.z) / u.z, t2z = (b.hz - C.z) / u.z;
+    double t1z = (b[2] - cz) / uz, t2z = (b[5] - cz) / uz;
     double tzMin = smin(t1z, t2z), tzMax = smax(t1z, t2z);
     double tMax = smin(txMax, smin(tyMax, tzMax));
     double tMin = smax(txMin, smax(tyMin, tzMin));
@@ -140,32 +144,52 @@ __device__ __noinline__ bool box_hit_exact(Box6 b, V3 C, V3 u) {
     return tMax > tMin;
 }
 
-/* The same decision as box_hit_exact, bit for bit, at a third of the cost. The slab parameters are
- * first formed with the reciprocal iu = 1/u (computed once per ray): (b - C) * iu differs from
- * (b - C) / u by at most 3 units in the last place, and min/max are monotone, so whenever
- * tMax and tMin are further apart than that error and tMax is not next to zero, the comparisons
- * "tMax < 0" and "tMax > tMin" come out as with true divisions. Everything else - a zero-thickness
- * box (tMax == tMin), a grazing ray, infinities or NaNs from a zero direction component - goes
- * through the true divisions. tnear receives the entry parameter of the box (-infinity when the
- * exact path decided, so that such a box is never pruned by distance). */
-__device__ __forceinline__ bool box_hit(Box6 b, V3 C, V3 u, V3 iu, double &tnear) {
-    double t1x = (b.lx - C.x) * iu.x, t2x = (b.hx - C.x) * iu.x;
-    double t1y = (b.ly - C.y) * iu.y, t2y = (b.hy - C.y) * iu.y;
-    double t1z = (b.lz - C.z) * iu.z, t2z = (b.hz - C.z) * iu.z;
-    /* fmin/fmax (one instruction each) agree with std::min/std::max on finite values; any infinity or
-     * NaN sends the box to the exact path below, so their different NaN rules never matter */
-    double tMax = fmin(fmax(t1x, t2x), fmin(fmax(t1y, t2y), fmax(t1z, t2z)));
-    double tMin = fmax(fmin(t1x, t2x), fmax(fmin(t1y, t2y), fmin(t1z, t2z)));
-    double gap = fabs(tMax - tMin), mag = fabs(tMax) + fabs(tMin);
-    /* (x - x) is 0 for finite x and NaN otherwise: one test for "all six are finite" */
-    double fin = (t1x - t1x) + (t2x - t2x) + (t1y - t1y) + (t2y - t2y) + (t1z - t1z) + (t2z - t2z);
-    bool sure = (fin == 0.0) && (gap > 4e-15 * mag) && (fabs(tMax) > 1e-290);
-    tnear = tMin;
-    if (!sure) {
-        tnear = -__builtin_huge_val();
-        return box_hit_exact(b, C, u);
-    }
-    return !(tMax < 0) && (tMax > tMin);
+/* Per-ray constants of the fast box test: iu = 1/u, nc = -(C * iu), and the tolerance below which the
+ * fast test does not decide. The slab parameter (b - C) / u of the reference is formed here as
+ * fma(b, iu, nc). With T the real-number value and M = max over the axes of (bmax + |C|) * |iu|:
+ *   |fma(b, iu, nc) - T| <= 2^-53 * (2 |T| + |C iu|) (1 + tiny),   |reference - T| <= 2^-53 * 2 |T| (1 + tiny),
+ * so the two differ by less than 5 * 2^-53 * M = 5.6e-16 M; min and max do not enlarge a difference.
+ * tol = 2e-15 M leaves a factor of three. Rays for which that bound cannot be trusted (a zero, huge,
+ * tiny or non-finite direction component or origin) get tol = NaN: no comparison with it holds and
+ * every one of their boxes goes to the exact test. */
+struct RayK {
+    V3 iu, nc;
+    double tol;
+};
+__device__ __forceinline__ RayK ray_constants(const DScene &sc, V3 C, V3 u) {
+    RayK k;
+    k.iu = mk(1.0 / u.x, 1.0 / u.y, 1.0 / u.z);
+    k.nc = mk(-(C.x * k.iu.x), -(C.y * k.iu.y), -(C.z * k.iu.z));
+    const double ax = fabs(k.iu.x), ay = fabs(k.iu.y), az = fabs(k.iu.z);
+    const double mx = (sc.bmax[0] + fabs(C.x)) * ax, my = (sc.bmax[1] + fabs(C.y)) * ay, mz = (sc.bmax[2] + fabs(C.z)) * az;
+    const bool ok = (mx < 1e200) && (my < 1e200) && (mz < 1e200) && (ax > 1e-200) && (ay > 1e-200) && (az > 1e-200) &&
+                    (ax < 1e200) && (ay < 1e200) && (az < 1e200) && (fabs(C.x) < 1e200) && (fabs(C.y) < 1e200) && (fabs(C.z) < 1e200);
+    const double m = fmax(mx, fmax(my, mz));
+    k.tol = ok ? 2e-15 * m : __builtin_nan("");
+    return k;
+}
+
+/* The decision of BoudingBox::intersect (raytracer.cpp:163-186: "tMax < 0 -> miss, else tMax > tMin")
+ * whenever it is beyond doubt: hit if both tMax - tMin and tMax exceed tol, miss if either is below
+ * -tol, otherwise `unsure` is set and the caller runs box_hit_exact. A zero-thickness box (tMax == tMin
+ * in the reference, never hit) is always unsure. tlo is a lower bound of the reference's tMin. */
+__device__ __forceinline__ void box_fast(const Box6 &b, const RayK &k, bool &hit, bool &unsure, double &tlo) {
+    const double t1x = __builtin_fma(b.lx, k.iu.x, k.nc.x), t2x = __builtin_fma(b.hx, k.iu.x, k.nc.x);
+    const double t1y = __builtin_fma(b.ly, k.iu.y, k.nc.y), t2y = __builtin_fma(b.hy, k.iu.y, k.nc.y);
+    const double t1z = __builtin_fma(b.lz, k.iu.z, k.nc.z), t2z = __builtin_fma(b.hz, k.iu.z, k.nc.z);
+    const double tMax = fmin(fmin(fmax(t1x, t2x), fmax(t1y, t2y)), fmax(t1z, t2z));
+    const double tMin = fmax(fmax(fmin(t1x, t2x), fmin(t1y, t2y)), fmin(t1z, t2z));
+    const double d = tMax - tMin;
+    hit = (d > k.tol) && (tMax > k.tol);
+    const bool miss = (d < -k.tol) || (tMax < -k.tol);
+    unsure = !(hit || miss);
+    tlo = tMin - k.tol;
+}
+
+/* a float that is certainly not above t (NaN for t beyond the float range: never "greater than" anything) */
+__device__ __forceinline__ float lower_float(double t) {
+    const float f = (float)t;
+    return __builtin_fmaf(-__builtin_fabsf(f), 0x1p-22f, f) - 0x1p-125f;
 }
 
 /* triangle test, raytracer.cpp:673-687 */
@@ -191,7 +215,8 @@ struct HitRec {
 
 /* ---- per-wave LDS ------------------------------------------------------------------------- */
 struct WaveLDS {
-    double ray[9][RT_WAVE];               /* C, u, 1/u of each lane's ray */
+    double ray[12][RT_WAVE];              /* C, u, 1/u, -(C/u) of each lane's ray */
+    double tol[RT_WAVE];                  /* below this the fast box test does not decide (NaN: never) */
     unsigned long long best_t[RT_WAVE];   /* bits of the smallest accepted triangle t (> 0, so the bit order is the value order) */
     double thr[RT_WAVE];                  /* distance beyond which nothing can change the ray's result */
     int32_t best_pos[RT_WAVE];            /* lowest triangle position among those with that t */
@@ -300,51 +325,68 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
         if (tmax < t0) t0 = tmax;
         if (!(t0 > 0)) t0 = 0; /* also turns -0.0 into +0.0: the bit pattern must order like the value */
     }
-    V3 iu = mk(1.0 / u.x, 1.0 / u.y, 1.0 / u.z);
-    w->ray[0][lane] = C.x; w->ray[1][lane] = C.y; w->ray[2][lane] = C.z;
-    w->ray[3][lane] = u.x; w->ray[4][lane] = u.y; w->ray[5][lane] = u.z;
-    w->ray[6][lane] = iu.x; w->ray[7][lane] = iu.y; w->ray[8][lane] = iu.z;
+    {
+        const RayK k = ray_constants(sc, C, u);
+        w->ray[0][lane] = C.x; w->ray[1][lane] = C.y; w->ray[2][lane] = C.z;
+        w->ray[3][lane] = u.x; w->ray[4][lane] = u.y; w->ray[5][lane] = u.z;
+        w->ray[6][lane] = k.iu.x; w->ray[7][lane] = k.iu.y; w->ray[8][lane] = k.iu.z;
+        w->ray[9][lane] = k.nc.x; w->ray[10][lane] = k.nc.y; w->ray[11][lane] = k.nc.z;
+        w->tol[lane] = k.tol;
+    }
     w->best_t[lane] = (unsigned long long)__double_as_longlong(t0);
     w->best_pos[lane] = INT32_MAX;
     w->thr[lane] = prune ? t0 * RT_PRUNE_SLACK : __builtin_huge_val();
     w->anyhit[lane] = (anyhit && prune) ? 1 : 0;
-    const double my_thr = prune ? t0 * RT_PRUNE_SLACK : __builtin_huge_val();
 
     int n_nodes = 0, n_leaves = 0; /* wave-uniform stack heights */
     int mi = 0;
-    while (mi < sc.n_meshes) {
-        /* root boxes (raytracer.cpp:644): every lane for its own ray; roots that pass enter the pool.
-         * Roots are fed in groups small enough for the stacks (at most RT_MESH_CHUNK meshes). */
-        const int root_budget = RT_WAVE * RT_MESH_CHUNK;
-        while (mi < sc.n_meshes && n_nodes + RT_WAVE <= root_budget && n_leaves + 4 * RT_WAVE <= RT_LEAF_CAP) {
-            const RootRec &m = roots[mi];
-            mi++;
-            bool pass = false;
-            double tn = 0;
-            if (active) {
-                if (CNT) cnt.box_tests++;
-                pass = box_hit(ldbox(m.box), C, u, iu, tn);
-                if (CNT && pass) cnt.mesh_calls++;
-                pass = pass && !(tn > my_thr);
-            }
-            const unsigned long long bal = __ballot(pass);
-            if (bal == 0ull) continue;
-            const int r = rank_in(bal);
-            if (m.root_count == 0) {
-                if (pass) w->node[n_nodes + r] = make_uint2((uint32_t)m.root | ((uint32_t)lane << RT_NODE_BITS), __float_as_uint(__double2float_rd(tn)));
-                n_nodes = uni(n_nodes + __popcll(bal));
-            } else { /* the root is itself a leaf */
-                if (pass) {
-                    w->leaf[n_leaves + r] = make_uint2((uint32_t)m.root, (uint32_t)m.root_count | ((uint32_t)lane << 26));
-                    w->leaf_t[n_leaves + r] = __double2float_rd(tn);
+    for (;;) {
+        /* Root boxes (raytracer.cpp:644): every lane for its own ray; roots that pass enter the pool. The
+         * next mesh is fed whenever fewer than RT_FEED_BELOW node items are pending, so the tail of one
+         * mesh's traversal shares its steps with the start of the next, and a root is already tested
+         * against the distance of the hits found so far. */
+        if (mi < sc.n_meshes && n_nodes < RT_FEED_BELOW && n_leaves <= RT_WAVE) {
+            RayK k;
+            k.iu = mk(w->ray[6][lane], w->ray[7][lane], w->ray[8][lane]);
+            k.nc = mk(w->ray[9][lane], w->ray[10][lane], w->ray[11][lane]);
+            k.tol = w->tol[lane];
+            const double my_thr = w->thr[lane];
+            do {
+                const RootRec &m = roots[mi];
+                mi++;
+                bool pass = false;
+                double tn = 0;
+                if (active) {
+                    if (CNT) cnt.box_tests++;
+                    bool unsure;
+                    box_fast(ldbox(m.box), k, pass, unsure, tn);
+                    if (__builtin_expect(unsure, 0)) {
+                        pass = box_hit_exact(m.box, C.x, C.y, C.z, u.x, u.y, u.z);
+                        tn = -__builtin_huge_val();
+                    }
+                    if (CNT && pass) cnt.mesh_calls++;
+                    pass = pass && !(tn > my_thr);
                 }
-                n_leaves = uni(n_leaves + __popcll(bal));
-            }
+                const unsigned long long bal = __ballot(pass);
+                if (bal == 0ull) continue;
+                const int r = rank_in(bal);
+                if (m.root_count == 0) {
+                    if (pass) w->node[n_nodes + r] = make_uint2((uint32_t)m.root | ((uint32_t)lane << RT_NODE_BITS), __float_as_uint(lower_float(tn)));
+                    n_nodes = uni(n_nodes + __popcll(bal));
+                } else { /* the root is itself a leaf */
+                    if (pass) {
+                        w->leaf[n_leaves + r] = make_uint2((uint32_t)m.root, (uint32_t)m.root_count | ((uint32_t)lane << 26));
+                        w->leaf_t[n_leaves + r] = lower_float(tn);
+                    }
+                    n_leaves = uni(n_leaves + __popcll(bal));
+                }
+            } while (mi < sc.n_meshes && n_nodes < RT_FEED_BELOW && n_leaves <= RT_WAVE);
+            wave_sync();
+            if (CNT) { uint64_t t = RT_STAMP(); cnt.cyc_roots += t - st0; st0 = t; }
         }
-        wave_sync();
-        if (CNT) { uint64_t t = RT_STAMP(); cnt.cyc_roots += t - st0; st0 = t; }
-        /* pool: until both stacks are empty, up to 64 items per step */
-        while (n_nodes + n_leaves > 0) {
+        if (n_nodes + n_leaves == 0) break; /* then every mesh has been fed: the feed runs whenever the pool is empty */
+        /* one pool step: up to 64 items */
+        {
             const bool do_leaf = (n_leaves >= RT_LEAF_TRIGGER) || (n_nodes == 0) || (n_leaves + 2 * RT_WAVE > RT_LEAF_CAP);
             if (do_leaf) {
                 /* 64 triangles per step whichever leaves they sit in: the top m <= 64 leaf items are
@@ -442,17 +484,28 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
                         atomicOr(sc.overflow, 2);
                     }
                 }
+                float fl = 0.f, fr = 0.f; /* entry parameters of the two children as the stacks keep them */
                 if (have) {
                     /* the whole 128-byte record in one batch of loads, before either box is tested */
                     const rt_bvh_node *nd = sc.nodes + (it.x & ((1u << RT_NODE_BITS) - 1u));
                     const Box6 bl = ldbox(nd->boxL), br = ldbox(nd->boxR);
                     L = nd->L; R = nd->R; nL = nd->nL; nR = nd->nR;
                     if (CNT) { cnt.nodes++; cnt.box_tests += 2; }
-                    V3 rc = mk(w->ray[0][rl], w->ray[1][rl], w->ray[2][rl]);
-                    V3 ru = mk(w->ray[3][rl], w->ray[4][rl], w->ray[5][rl]);
-                    V3 ri = mk(w->ray[6][rl], w->ray[7][rl], w->ray[8][rl]);
-                    const bool hl = box_hit(bl, rc, ru, ri, tl) && !(tl > thr);
-                    const bool hr = box_hit(br, rc, ru, ri, tr) && !(tr > thr);
+                    RayK rk;
+                    rk.iu = mk(w->ray[6][rl], w->ray[7][rl], w->ray[8][rl]);
+                    rk.nc = mk(w->ray[9][rl], w->ray[10][rl], w->ray[11][rl]);
+                    rk.tol = w->tol[rl];
+                    bool hl, hr, ul, ur;
+                    box_fast(bl, rk, hl, ul, tl);
+                    box_fast(br, rk, hr, ur, tr);
+                    if (__builtin_expect(ul || ur, 0)) { /* rare: true divisions, as the reference does them */
+                        const double cx = w->ray[0][rl], cy = w->ray[1][rl], cz = w->ray[2][rl];
+                        const double ux = w->ray[3][rl], uy = w->ray[4][rl], uz = w->ray[5][rl];
+                        if (ul) { hl = box_hit_exact(nd->boxL, cx, cy, cz, ux, uy, uz); tl = -__builtin_huge_val(); }
+                        if (ur) { hr = box_hit_exact(nd->boxR, cx, cy, cz, ux, uy, uz); tr = -__builtin_huge_val(); }
+                    }
+                    hl = hl && !(tl > thr);
+                    hr = hr && !(tr > thr);
                     pnl = hl && nL == 0; pll = hl && nL > 0;
                     pnr = hr && nR == 0; plr = hr && nR > 0;
                     /* the nearer child goes on top of the stack: it is popped first */
@@ -460,26 +513,28 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
                         const int32_t ti = L; L = R; R = ti;
                         const double td = tl; tl = tr; tr = td;
                     }
+                    fl = lower_float(tl);
+                    fr = lower_float(tr);
                 }
                 const unsigned long long b0 = __ballot(pnl), b1 = __ballot(pnr), b2 = __ballot(pll), b3 = __ballot(plr);
                 const int c0 = __popcll(b0), c1 = __popcll(b1);
                 if (n_nodes + c0 + c1 > sc.node_cap) { /* cannot happen for a validated scene; never write past the stack */
                     if (lane == 0) atomicOr(sc.overflow, 1);
                 } else {
-                    if (pnl) w->node[n_nodes + rank_in(b0)] = make_uint2((uint32_t)L | ((uint32_t)rl << RT_NODE_BITS), __float_as_uint(__double2float_rd(tl)));
-                    if (pnr) w->node[n_nodes + c0 + rank_in(b1)] = make_uint2((uint32_t)R | ((uint32_t)rl << RT_NODE_BITS), __float_as_uint(__double2float_rd(tr)));
+                    if (pnl) w->node[n_nodes + rank_in(b0)] = make_uint2((uint32_t)L | ((uint32_t)rl << RT_NODE_BITS), __float_as_uint(fl));
+                    if (pnr) w->node[n_nodes + c0 + rank_in(b1)] = make_uint2((uint32_t)R | ((uint32_t)rl << RT_NODE_BITS), __float_as_uint(fr));
                     n_nodes = uni(n_nodes + c0 + c1);
                 }
                 const int c2 = __popcll(b2);
                 if (pll) {
                     const int q = n_leaves + rank_in(b2);
                     w->leaf[q] = make_uint2((uint32_t)L, (uint32_t)nL | ((uint32_t)rl << 26));
-                    w->leaf_t[q] = __double2float_rd(tl);
+                    w->leaf_t[q] = fl;
                 }
                 if (plr) {
                     const int q = n_leaves + c2 + rank_in(b3);
                     w->leaf[q] = make_uint2((uint32_t)R, (uint32_t)nR | ((uint32_t)rl << 26));
-                    w->leaf_t[q] = __double2float_rd(tr);
+                    w->leaf_t[q] = fr;
                 }
                 n_leaves = uni(n_leaves + c2 + __popcll(b3));
                 wave_sync();
