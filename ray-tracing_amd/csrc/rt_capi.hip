@@ -16,7 +16,7 @@
 
 using namespace rtd;
 
-#define RT_COUNTER_WORDS 20 /* rt_counters (8 words) + 12 diagnostic words of rt_device.hip.h */
+#define RT_COUNTER_WORDS 28 /* rt_counters (8 words) + 20 diagnostic words of rt_device.hip.h */
 #define RT_BLOCK 64 /* one workgroup = one wave: the LDS pool of rt_device.hip.h is per wave */
 #ifndef RT_WAVES_PER_SIMD
 #define RT_WAVES_PER_SIMD 2 /* resident waves per SIMD the render kernel is compiled for (register budget 512 / this) */
@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_intersect_kernel(DScene sc, const
     bool ok = scene_closest_wave<false>(sc, w, sph, roots, live, C, u, 1E10, false, prune != 0, h, cnt);
     if (!live) return;
     obj_id[q] = ok ? h.obj : -1;
-    tri_id[q] = (ok && h.mesh >= 0) ? sc.tris[h.prim].orig_id : -1;
+    tri_id[q] = (ok && h.mesh >= 0) ? sc.tri_orig[h.prim] : -1;
     t[q] = h.t;
     Surf s;
     s.P = s.N = s.albedo = mk(0, 0, 0);
@@ -483,8 +483,46 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
     int rc;
     if ((rc = upload_array(c, s->spheres, (size_t)s->n_spheres, &d.spheres))) return rc;
     if ((rc = upload_array(c, s->meshes, (size_t)s->n_meshes, &d.meshes))) return rc;
-    if ((rc = upload_array(c, s->nodes, (size_t)s->n_nodes, &d.nodes))) return rc;
-    if ((rc = upload_array(c, s->tris, (size_t)s->n_tris, &d.tris))) return rc;
+    {
+        /* device layouts (rt_device.hip.h): every BVH record as two 64-byte halves, triangles as nine coordinate arrays */
+        std::vector<NodeHalf> halves((size_t)s->n_nodes * 2);
+        for (int64_t k = 0; k < s->n_nodes; k++) {
+            const rt_bvh_node &nd = s->nodes[k];
+            NodeHalf &l = halves[(size_t)k * 2], &r = halves[(size_t)k * 2 + 1];
+            memset(&l, 0, sizeof l);
+            memset(&r, 0, sizeof r);
+            for (int q = 0; q < 6; q++) { l.box[q] = nd.boxL[q]; r.box[q] = nd.boxR[q]; }
+            l.child = nd.L; l.count = nd.nL;
+            r.child = nd.R; r.count = nd.nR;
+        }
+        std::vector<NodeRec32> rec32((size_t)s->n_nodes);
+        for (int64_t k = 0; k < s->n_nodes; k++) {
+            const rt_bvh_node &nd = s->nodes[k];
+            for (int a = 0; a < 6; a++) { rec32[(size_t)k].boxL[a] = (float)nd.boxL[a]; rec32[(size_t)k].boxR[a] = (float)nd.boxR[a]; }
+            rec32[(size_t)k].L = nd.L; rec32[(size_t)k].R = nd.R;
+            rec32[(size_t)k].nL = nd.nL; rec32[(size_t)k].nR = nd.nR;
+        }
+        if ((rc = upload_array(c, rec32.data(), rec32.size(), &d.rec32))) return rc;
+        const int64_t stride = (s->n_tris + 15) & ~(int64_t)15;
+        std::vector<double> soa((size_t)stride * 9, 0.0);
+        std::vector<int32_t> tmesh((size_t)s->n_tris), torig((size_t)s->n_tris);
+        for (int64_t k = 0; k < s->n_tris; k++) {
+            const rt_tri &t = s->tris[k];
+            for (int q = 0; q < 3; q++) {
+                soa[(size_t)(q * stride + k)] = t.A[q];
+                soa[(size_t)((3 + q) * stride + k)] = t.e1[q];
+                soa[(size_t)((6 + q) * stride + k)] = t.e2[q];
+            }
+            tmesh[(size_t)k] = t.mesh;
+            torig[(size_t)k] = t.orig_id;
+        }
+        d.tri_stride = stride;
+        if ((rc = upload_array(c, halves.data(), halves.size(), &d.halves))) return rc;
+        if ((rc = upload_array(c, soa.data(), soa.size(), &d.tri_soa))) return rc;
+        if ((rc = upload_array(c, tmesh.data(), tmesh.size(), &d.tri_mesh))) return rc;
+        if ((rc = upload_array(c, torig.data(), torig.size(), &d.tri_orig))) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream)); /* the staging vectors go out of scope */
+    }
     if ((rc = upload_array(c, s->attrs, (size_t)s->n_tris, &d.attrs))) return rc;
     if ((rc = upload_array(c, s->tex, (size_t)s->n_tex, &d.tex))) return rc;
     if ((rc = upload_array(c, s->texels, (size_t)s->texel_bytes, &d.texels))) return rc;
@@ -795,12 +833,12 @@ int rt_get_counters(rt_ctx *c, rt_counters *out) {
     return RT_OK;
 }
 
-/* not part of the public header: 12 diagnostic words of the counted kernel variant (cycle stamps per
- * phase and pool occupancy), for tools/ only */
-int rt_debug_stats(rt_ctx *c, uint64_t *out12) {
-    if (!c || !out12) return RT_E_INVALID;
+/* not part of the public header: 20 diagnostic words of the counted kernel variant (cycle stamps per
+ * phase, pool occupancy, 8 free slots for experiments), for tools/ only */
+int rt_debug_stats(rt_ctx *c, uint64_t *out20) {
+    if (!c || !out20) return RT_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(out12, reinterpret_cast<uint64_t *>(c->d_counters) + 8, 12 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out20, reinterpret_cast<uint64_t *>(c->d_counters) + 8, 20 * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }

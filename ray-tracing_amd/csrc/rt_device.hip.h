@@ -51,12 +51,35 @@ struct RootRec {
     int32_t pad[2];
 };
 
+/* Device form of one child of a BVH record (rt_bvh_node of rt_amd.h is repacked at upload): the two
+ * children of record r are halves 2r and 2r+1, 64 bytes each, so that a pair of lanes fetches one
+ * record with each lane reading only the box it tests. */
+struct NodeHalf {
+    double box[6];
+    int32_t child; /* inner child: record index; leaf: first triangle position */
+    int32_t count; /* 0 for an inner child, else the leaf's triangle count */
+    int32_t pad[2];
+};
+
+/* What the traversal reads: one 64-byte record per BVH node with both child boxes rounded to float. The
+ * fast box test decides on these and allows for the rounding in its tolerance; only an undecided test
+ * reads the double box of NodeHalf. */
+struct NodeRec32 {
+    float boxL[6], boxR[6];
+    int32_t L, R, nL, nR;
+};
+
 struct DScene {
     const rt_sphere *spheres;
     const RootRec *roots;
     const rt_mesh *meshes;
-    const rt_bvh_node *nodes;
-    const rt_tri *tris;
+    const NodeHalf *halves;   /* 2 per BVH record */
+    const NodeRec32 *rec32;   /* 1 per BVH record, boxes in float */
+    const double *tri_soa;    /* 9 arrays of tri_stride doubles: A.x A.y A.z e1.x e1.y e1.z e2.x e2.y e2.z by triangle position,
+                                 so that lanes testing consecutive triangles read consecutive addresses */
+    const int32_t *tri_mesh;  /* mesh index by triangle position */
+    const int32_t *tri_orig;  /* index into the caller's triangle list by triangle position */
+    int64_t tri_stride;
     const rt_tri_attr *attrs;
     const rt_texture *tex;
     const uint8_t *texels;
@@ -123,8 +146,12 @@ struct Cnt {
     /* diagnostic build only (RT_F_COUNTERS): wave-level cycle stamps and pool occupancy */
     uint64_t cyc_fresh, cyc_roots, cyc_node, cyc_leaf, cyc_finish, cyc_shade;
     uint64_t node_steps, node_lanes, leaf_steps, leaf_lanes, queries, query_lanes;
+    uint64_t dbg[8];
 };
 #define RT_STAMP() ((uint64_t)__builtin_amdgcn_s_memtime())
+#ifndef RT_STAMP_STEPS
+#define RT_STAMP_STEPS 0 /* 1: the counted kernel also times the parts of a pool step (it then waits for the loads where it stamps) */
+#endif
 
 /* BoudingBox::intersect, raytracer.cpp:163-186 (six true divisions, no bound on t) */
 struct Box6 {
@@ -146,12 +173,15 @@ __device__ __noinline__ bool box_hit_exact(const double *b, double cx, double cy
 
 /* Per-ray constants of the fast box test: iu = 1/u, nc = -(C * iu), and the tolerance below which the
  * fast test does not decide. The slab parameter (b - C) / u of the reference is formed here as
- * fma(b, iu, nc). With T the real-number value and M = max over the axes of (bmax + |C|) * |iu|:
- *   |fma(b, iu, nc) - T| <= 2^-53 * (2 |T| + |C iu|) (1 + tiny),   |reference - T| <= 2^-53 * 2 |T| (1 + tiny),
- * so the two differ by less than 5 * 2^-53 * M = 5.6e-16 M; min and max do not enlarge a difference.
- * tol = 2e-15 M leaves a factor of three. Rays for which that bound cannot be trusted (a zero, huge,
- * tiny or non-finite direction component or origin) get tol = NaN: no comparison with it holds and
- * every one of their boxes goes to the exact test. */
+ * fma(b', iu, nc), where b' is the box coordinate b rounded to float (|b' - b| <= 2^-24 |b|; mesh root
+ * boxes are used unrounded). With T the real-number value and M = max over the axes of
+ * (bmax + |C|) * |iu|:
+ *   |fma(b', iu, nc) - T| <= 2^-24 |b iu| + 2^-53 (2 |T| + |C iu|) (1 + tiny),   |reference - T| <= 2^-53 * 2 |T| (1 + tiny),
+ * so the two differ by less than 6.0e-8 M; min and max do not enlarge a difference. tol = 1.3e-7 M
+ * covers that twice over (the test compares tMax - tMin, which carries two such errors). Rays for which
+ * the bound cannot be trusted (a zero, huge, tiny or non-finite direction component or origin, or a
+ * scene whose boxes do not fit a float) get tol = NaN: no comparison with it holds and every one of
+ * their boxes goes to the exact test. */
 struct RayK {
     V3 iu, nc;
     double tol;
@@ -162,10 +192,10 @@ __device__ __forceinline__ RayK ray_constants(const DScene &sc, V3 C, V3 u) {
     k.nc = mk(-(C.x * k.iu.x), -(C.y * k.iu.y), -(C.z * k.iu.z));
     const double ax = fabs(k.iu.x), ay = fabs(k.iu.y), az = fabs(k.iu.z);
     const double mx = (sc.bmax[0] + fabs(C.x)) * ax, my = (sc.bmax[1] + fabs(C.y)) * ay, mz = (sc.bmax[2] + fabs(C.z)) * az;
-    const bool ok = (mx < 1e200) && (my < 1e200) && (mz < 1e200) && (ax > 1e-200) && (ay > 1e-200) && (az > 1e-200) &&
+    const bool ok = (sc.bmax[0] < 1e30) && (sc.bmax[1] < 1e30) && (sc.bmax[2] < 1e30) && (mx < 1e30) && (my < 1e30) && (mz < 1e30) && (ax > 1e-200) && (ay > 1e-200) && (az > 1e-200) &&
                     (ax < 1e200) && (ay < 1e200) && (az < 1e200) && (fabs(C.x) < 1e200) && (fabs(C.y) < 1e200) && (fabs(C.z) < 1e200);
     const double m = fmax(mx, fmax(my, mz));
-    k.tol = ok ? 2e-15 * m : __builtin_nan("");
+    k.tol = ok ? 1.3e-7 * m : __builtin_nan("");
     return k;
 }
 
@@ -193,15 +223,34 @@ __device__ __forceinline__ float lower_float(double t) {
 }
 
 /* triangle test, raytracer.cpp:673-687 */
-__device__ __forceinline__ bool tri_test(const rt_tri *tr, V3 C, V3 u, double &beta, double &gamma, double &localt) {
-    V3 A = ld3(tr->A), e1 = ld3(tr->e1), e2 = ld3(tr->e2);
-    V3 N = cross(e1, e2), AO = sub(C, A), AOu = cross(AO, u);
+/* keeps a value in a register at this point: what produces it cannot be moved below, what uses it not above */
+__device__ __forceinline__ void pin(double &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin3(V3 &a) { pin(a.x); pin(a.y); pin(a.z); }
+
+struct Tri3 {
+    V3 A, e1, e2;
+};
+__device__ __forceinline__ Tri3 tri_load(const DScene &sc, uint32_t pos) {
+    const double *p = sc.tri_soa + pos;
+    const int64_t n = sc.tri_stride;
+    Tri3 t;
+    t.A = mk(p[0], p[n], p[2 * n]);
+    t.e1 = mk(p[3 * n], p[4 * n], p[5 * n]);
+    t.e2 = mk(p[6 * n], p[7 * n], p[8 * n]);
+    return t;
+}
+__device__ __forceinline__ bool tri_eval(const Tri3 &t, V3 C, V3 u, double &beta, double &gamma, double &localt) {
+    V3 N = cross(t.e1, t.e2), AO = sub(C, t.A), AOu = cross(AO, u);
     double invUN = 1. / dot(u, N);
-    beta = -dot(e2, AOu) * invUN;
-    gamma = dot(e1, AOu) * invUN;
+    beta = -dot(t.e2, AOu) * invUN;
+    gamma = dot(t.e1, AOu) * invUN;
     double alpha = 1 - beta - gamma;
     localt = -dot(AO, N) * invUN;
     return beta >= 0 && gamma >= 0 && beta <= 1 && gamma <= 1 && alpha >= 0 && localt > 0;
+}
+__device__ __forceinline__ bool tri_test(const DScene &sc, uint32_t pos, V3 C, V3 u, double &beta, double &gamma, double &localt) {
+    const Tri3 t = tri_load(sc, pos);
+    return tri_eval(t, C, u, beta, gamma, localt);
 }
 
 /* closest hit, in the form that lets the attributes be computed once at the end */
@@ -428,13 +477,26 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
                 const int k = take;
                 bool acc = false;
                 double beta, gamma, lt = 0;
+                bool ok = have;
                 if (have && tri >= sc.n_tris_total) { /* never fetch outside the arrays */
                     atomicOr(sc.overflow, 2);
-                } else if (have) {
+                    ok = false;
+                }
+                /* all nine coordinate loads and the ray's LDS reads are issued before anything is waited for:
+                 * unconditional (a lane without a triangle reads triangle 0), fenced, then pinned */
+                Tri3 tv = tri_load(sc, ok ? tri : 0u);
+                V3 rc = mk(w->ray[0][rl], w->ray[1][rl], w->ray[2][rl]);
+                V3 ru = mk(w->ray[3][rl], w->ray[4][rl], w->ray[5][rl]);
+                asm volatile("" ::: "memory");
+                pin3(tv.A); pin3(tv.e1); pin3(tv.e2); pin3(rc); pin3(ru);
+                if (CNT && RT_STAMP_STEPS) {
+                    uint64_t t = RT_STAMP(); cnt.dbg[4] += t - st0;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    uint64_t t2 = RT_STAMP(); cnt.dbg[5] += t2 - t;
+                }
+                if (ok) {
                     if (CNT) cnt.tris++;
-                    V3 rc = mk(w->ray[0][rl], w->ray[1][rl], w->ray[2][rl]);
-                    V3 ru = mk(w->ray[3][rl], w->ray[4][rl], w->ray[5][rl]);
-                    acc = tri_test(sc.tris + tri, rc, ru, beta, gamma, lt);
+                    acc = tri_eval(tv, rc, ru, beta, gamma, lt);
                 }
                 if (__ballot(acc) != 0ull) {
                     /* keep (min t, then min position) per ray. LDS executes one wave's instructions in
@@ -459,62 +521,58 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
                 wave_sync();
                 if (CNT) { uint64_t t = RT_STAMP(); cnt.cyc_leaf += t - st0; st0 = t; cnt.leaf_steps++; cnt.leaf_lanes += (uint64_t)k; }
             } else {
-                /* one BVH record per lane: test both child boxes (raytracer.cpp:656-665), push the hit ones.
-                 * Up to 64 records per step while the stack is below RT_NODE_SOFT (a step can add one
-                 * entry per record popped); above it one record per step, a plain depth-first descent
-                 * that needs at most max_depth + 1 entries more. */
+                /* Up to 64 BVH records per step, one per lane: both child boxes are tested (raytracer.cpp:656-665)
+                 * and the children that are hit are pushed. 64 records are popped while the stack is below
+                 * RT_NODE_SOFT (a step can add one entry per record popped); above it one record per step,
+                 * a plain depth-first descent that needs at most max_depth + 1 entries more.
+                 * Branch-free up to the box decisions, so that all loads of the step are in flight before the
+                 * first is waited for: a lane without a record reads slot 0 / record 0 and is masked out. */
                 int k = n_nodes < RT_WAVE ? n_nodes : RT_WAVE;
                 const int room = RT_NODE_SOFT - n_nodes;
                 if (k > room) k = room > 1 ? room : 1;
                 bool have = lane < k;
-                uint2 it = make_uint2(0u, 0u);
-                if (have) it = w->node[n_nodes - 1 - lane];
+                const uint2 it = w->node[have ? n_nodes - 1 - lane : 0];
                 n_nodes -= k;
                 wave_sync();
                 const int rl = (int)(it.x >> RT_NODE_BITS);
-                bool pnl = false, pnr = false, pll = false, plr = false;
-                int32_t L = 0, R = 0, nL = 0, nR = 0;
-                double tl = 0, tr = 0;
-                double thr = 0;
-                if (have) {
-                    thr = w->thr[rl];
-                    have = !((double)__uint_as_float(it.y) > thr); /* fallen behind the threshold since it was pushed */
-                    if ((it.x & ((1u << RT_NODE_BITS) - 1u)) >= sc.n_nodes_total) { /* never fetch outside the arrays */
-                        have = false;
-                        atomicOr(sc.overflow, 2);
-                    }
+                uint32_t rec = it.x & ((1u << RT_NODE_BITS) - 1u);
+                if (have && rec >= sc.n_nodes_total) { /* never fetch outside the arrays */
+                    have = false;
+                    atomicOr(sc.overflow, 2);
                 }
-                float fl = 0.f, fr = 0.f; /* entry parameters of the two children as the stacks keep them */
-                if (have) {
-                    /* the whole 128-byte record in one batch of loads, before either box is tested */
-                    const rt_bvh_node *nd = sc.nodes + (it.x & ((1u << RT_NODE_BITS) - 1u));
-                    const Box6 bl = ldbox(nd->boxL), br = ldbox(nd->boxR);
-                    L = nd->L; R = nd->R; nL = nd->nL; nR = nd->nR;
-                    if (CNT) { cnt.nodes++; cnt.box_tests += 2; }
-                    RayK rk;
-                    rk.iu = mk(w->ray[6][rl], w->ray[7][rl], w->ray[8][rl]);
-                    rk.nc = mk(w->ray[9][rl], w->ray[10][rl], w->ray[11][rl]);
-                    rk.tol = w->tol[rl];
-                    bool hl, hr, ul, ur;
-                    box_fast(bl, rk, hl, ul, tl);
-                    box_fast(br, rk, hr, ur, tr);
-                    if (__builtin_expect(ul || ur, 0)) { /* rare: true divisions, as the reference does them */
-                        const double cx = w->ray[0][rl], cy = w->ray[1][rl], cz = w->ray[2][rl];
-                        const double ux = w->ray[3][rl], uy = w->ray[4][rl], uz = w->ray[5][rl];
-                        if (ul) { hl = box_hit_exact(nd->boxL, cx, cy, cz, ux, uy, uz); tl = -__builtin_huge_val(); }
-                        if (ur) { hr = box_hit_exact(nd->boxR, cx, cy, cz, ux, uy, uz); tr = -__builtin_huge_val(); }
-                    }
-                    hl = hl && !(tl > thr);
-                    hr = hr && !(tr > thr);
-                    pnl = hl && nL == 0; pll = hl && nL > 0;
-                    pnr = hr && nR == 0; plr = hr && nR > 0;
-                    /* the nearer child goes on top of the stack: it is popped first */
-                    if (pnl && pnr && tl < tr) {
-                        const int32_t ti = L; L = R; R = ti;
-                        const double td = tl; tl = tr; tr = td;
-                    }
-                    fl = lower_float(tl);
-                    fr = lower_float(tr);
+                if (!have) rec = 0;
+                const float4 *rp = reinterpret_cast<const float4 *>(sc.rec32 + rec);
+                const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
+                const double thr = w->thr[rl];
+                RayK rk;
+                rk.iu = mk(w->ray[6][rl], w->ray[7][rl], w->ray[8][rl]);
+                rk.nc = mk(w->ray[9][rl], w->ray[10][rl], w->ray[11][rl]);
+                rk.tol = w->tol[rl];
+                have = have && !((double)__uint_as_float(it.y) > thr); /* fallen behind the threshold since it was pushed */
+                if (CNT && have) { cnt.nodes++; cnt.box_tests += 2; }
+                int32_t L = __float_as_int(q3.x), R = __float_as_int(q3.y);
+                const int32_t nL = __float_as_int(q3.z), nR = __float_as_int(q3.w);
+                const Box6 bl = Box6{(double)q0.x, (double)q0.y, (double)q0.z, (double)q0.w, (double)q1.x, (double)q1.y};
+                const Box6 br = Box6{(double)q1.z, (double)q1.w, (double)q2.x, (double)q2.y, (double)q2.z, (double)q2.w};
+                bool hl, hr, ul, ur;
+                double tl, tr;
+                box_fast(bl, rk, hl, ul, tl);
+                box_fast(br, rk, hr, ur, tr);
+                if (__builtin_expect(have && (ul || ur), 0)) { /* rare: the double boxes and true divisions, as the reference does them */
+                    const double cx = w->ray[0][rl], cy = w->ray[1][rl], cz = w->ray[2][rl];
+                    const double ux = w->ray[3][rl], uy = w->ray[4][rl], uz = w->ray[5][rl];
+                    if (ul) { hl = box_hit_exact(sc.halves[(size_t)rec * 2].box, cx, cy, cz, ux, uy, uz); tl = -__builtin_huge_val(); }
+                    if (ur) { hr = box_hit_exact(sc.halves[(size_t)rec * 2 + 1].box, cx, cy, cz, ux, uy, uz); tr = -__builtin_huge_val(); }
+                }
+                hl = have && hl && !(tl > thr);
+                hr = have && hr && !(tr > thr);
+                const bool pnl = hl && nL == 0, pll = hl && nL > 0;
+                const bool pnr = hr && nR == 0, plr = hr && nR > 0;
+                float fl = lower_float(tl), fr = lower_float(tr);
+                /* the nearer child goes on top of the stack: it is popped first */
+                if (pnl && pnr && fl < fr) {
+                    const int32_t ti = L; L = R; R = ti;
+                    const float tf = fl; fl = fr; fr = tf;
                 }
                 const unsigned long long b0 = __ballot(pnl), b1 = __ballot(pnr), b2 = __ballot(pll), b3 = __ballot(plr);
                 const int c0 = __popcll(b0), c1 = __popcll(b1);
@@ -547,12 +605,12 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
         const double tm = __longlong_as_double((long long)w->best_t[lane]);
         const int32_t pos = w->best_pos[lane];
         if (pos != INT32_MAX) {
-            const int32_t mi2 = sc.tris[pos].mesh;
+            const int32_t mi2 = sc.tri_mesh[pos];
             const int32_t oid = sc.meshes[mi2].object_id;
             if (tm < h.t || (tm == h.t && oid < h.obj)) {
                 h.t = tm; h.obj = oid; h.prim = pos; h.mesh = mi2;
                 double lt;
-                (void)tri_test(sc.tris + pos, C, u, h.beta, h.gamma, lt); /* alpha, beta, gamma of the winner (:683-685) */
+                (void)tri_test(sc, (uint32_t)pos, C, u, h.beta, h.gamma, lt); /* alpha, beta, gamma of the winner (:683-685) */
             }
         }
     }
@@ -923,8 +981,10 @@ __device__ __forceinline__ void flush_counters(const Cnt &c, rt_counters *out) {
     /* wave-level diagnostics: identical in every lane, lane 0 adds them behind the public counters */
     uint64_t d[12] = {c.cyc_fresh, c.cyc_roots, c.cyc_node, c.cyc_leaf, c.cyc_finish, c.cyc_shade,
                       c.node_steps, c.node_lanes, c.leaf_steps, c.leaf_lanes, c.queries, c.query_lanes};
-    if ((threadIdx.x & 63) == 0)
+    if ((threadIdx.x & 63) == 0) {
         for (int q = 0; q < 12; q++) atomicAdd(o + 8 + q, (unsigned long long)d[q]);
+        for (int q = 0; q < 8; q++) atomicAdd(o + 20 + q, (unsigned long long)c.dbg[q]);
+    }
 }
 
 } // namespace rtd
