@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_intersect_kernel(DScene sc, const
     bool ok = scene_closest_wave<false>(sc, w, sph, roots, live, C, u, 1E10, false, prune != 0, h, cnt);
     if (!live) return;
     obj_id[q] = ok ? h.obj : -1;
-    tri_id[q] = (ok && h.mesh >= 0) ? sc.tri_orig[h.prim] : -1;
+    tri_id[q] = (ok && h.mesh >= 0) ? sc.tris[h.prim].orig_id : -1;
     t[q] = h.t;
     Surf s;
     s.P = s.N = s.albedo = mk(0, 0, 0);
@@ -484,7 +484,7 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
     if ((rc = upload_array(c, s->spheres, (size_t)s->n_spheres, &d.spheres))) return rc;
     if ((rc = upload_array(c, s->meshes, (size_t)s->n_meshes, &d.meshes))) return rc;
     {
-        /* device layouts (rt_device.hip.h): every BVH record as two 64-byte halves, triangles as nine coordinate arrays */
+        /* device layouts (rt_device.hip.h): every BVH record as one float record plus two double halves */
         std::vector<NodeHalf> halves((size_t)s->n_nodes * 2);
         for (int64_t k = 0; k < s->n_nodes; k++) {
             const rt_bvh_node &nd = s->nodes[k];
@@ -503,24 +503,8 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
             rec32[(size_t)k].nL = nd.nL; rec32[(size_t)k].nR = nd.nR;
         }
         if ((rc = upload_array(c, rec32.data(), rec32.size(), &d.rec32))) return rc;
-        const int64_t stride = (s->n_tris + 15) & ~(int64_t)15;
-        std::vector<double> soa((size_t)stride * 9, 0.0);
-        std::vector<int32_t> tmesh((size_t)s->n_tris), torig((size_t)s->n_tris);
-        for (int64_t k = 0; k < s->n_tris; k++) {
-            const rt_tri &t = s->tris[k];
-            for (int q = 0; q < 3; q++) {
-                soa[(size_t)(q * stride + k)] = t.A[q];
-                soa[(size_t)((3 + q) * stride + k)] = t.e1[q];
-                soa[(size_t)((6 + q) * stride + k)] = t.e2[q];
-            }
-            tmesh[(size_t)k] = t.mesh;
-            torig[(size_t)k] = t.orig_id;
-        }
-        d.tri_stride = stride;
         if ((rc = upload_array(c, halves.data(), halves.size(), &d.halves))) return rc;
-        if ((rc = upload_array(c, soa.data(), soa.size(), &d.tri_soa))) return rc;
-        if ((rc = upload_array(c, tmesh.data(), tmesh.size(), &d.tri_mesh))) return rc;
-        if ((rc = upload_array(c, torig.data(), torig.size(), &d.tri_orig))) return rc;
+        if ((rc = upload_array(c, s->tris, (size_t)s->n_tris, &d.tris))) return rc;
         HIPCHK(c, hipStreamSynchronize(c->stream)); /* the staging vectors go out of scope */
     }
     if ((rc = upload_array(c, s->attrs, (size_t)s->n_tris, &d.attrs))) return rc;
@@ -530,7 +514,7 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
         std::vector<RootRec> rr((size_t)s->n_meshes);
         for (int mi = 0; mi < s->n_meshes; mi++) {
             memset(&rr[mi], 0, sizeof(RootRec));
-            for (int k = 0; k < 6; k++) rr[mi].box[k] = s->meshes[mi].root_box[k];
+            for (int k = 0; k < 6; k++) rr[mi].box[k] = (float)s->meshes[mi].root_box[k];
             rr[mi].root = s->meshes[mi].root;
             rr[mi].root_count = s->meshes[mi].root_count;
         }

@@ -39,16 +39,17 @@ namespace rtd {
 #ifndef RT_NODE_SOFT
 #define RT_NODE_SOFT 512
 #endif          /* node-item stack height up to which 64 items are popped per step */
+#ifndef RT_LEAF_CAP
 #define RT_LEAF_CAP 256           /* leaf-item stack entries */
+#endif
 #define RT_LEAF_TRIGGER 24        /* pending leaf items that make the next pool step a triangle step */
 #define RT_NODE_BITS 26           /* node index bits in a node item (the ray lane takes the top 6) */
 #define RT_MAX_DEPTH 60
 
 /* what the root phase needs of a mesh: the root box (raytracer.cpp:644) and where the tree starts */
-struct RootRec {
-    double box[6];
+struct RootRec { /* 32 bytes; the box rounded to float like NodeRec32, the double box stays in rt_mesh */
+    float box[6];
     int32_t root, root_count;
-    int32_t pad[2];
 };
 
 /* Device form of one child of a BVH record (rt_bvh_node of rt_amd.h is repacked at upload): the two
@@ -75,11 +76,7 @@ struct DScene {
     const rt_mesh *meshes;
     const NodeHalf *halves;   /* 2 per BVH record */
     const NodeRec32 *rec32;   /* 1 per BVH record, boxes in float */
-    const double *tri_soa;    /* 9 arrays of tri_stride doubles: A.x A.y A.z e1.x e1.y e1.z e2.x e2.y e2.z by triangle position,
-                                 so that lanes testing consecutive triangles read consecutive addresses */
-    const int32_t *tri_mesh;  /* mesh index by triangle position */
-    const int32_t *tri_orig;  /* index into the caller's triangle list by triangle position */
-    int64_t tri_stride;
+    const rt_tri *tris;       /* by triangle position (80 bytes each: a leaf's triangles are contiguous) */
     const rt_tri_attr *attrs;
     const rt_texture *tex;
     const uint8_t *texels;
@@ -231,12 +228,11 @@ struct Tri3 {
     V3 A, e1, e2;
 };
 __device__ __forceinline__ Tri3 tri_load(const DScene &sc, uint32_t pos) {
-    const double *p = sc.tri_soa + pos;
-    const int64_t n = sc.tri_stride;
+    const rt_tri *tr = sc.tris + pos;
     Tri3 t;
-    t.A = mk(p[0], p[n], p[2 * n]);
-    t.e1 = mk(p[3 * n], p[4 * n], p[5 * n]);
-    t.e2 = mk(p[6 * n], p[7 * n], p[8 * n]);
+    t.A = ld3(tr->A);
+    t.e1 = ld3(tr->e1);
+    t.e2 = ld3(tr->e2);
     return t;
 }
 __device__ __forceinline__ bool tri_eval(const Tri3 &t, V3 C, V3 u, double &beta, double &gamma, double &localt) {
@@ -265,11 +261,11 @@ struct HitRec {
 /* ---- per-wave LDS ------------------------------------------------------------------------- */
 struct WaveLDS {
     double ray[12][RT_WAVE];              /* C, u, 1/u, -(C/u) of each lane's ray */
-    double tol[RT_WAVE];                  /* below this the fast box test does not decide (NaN: never) */
+    double tol[RT_WAVE];                  /* |tol|: below this the fast box test does not decide (NaN: never). The sign bit is set
+                                             when the caller only asks whether something is hit before tmax */
     unsigned long long best_t[RT_WAVE];   /* bits of the smallest accepted triangle t (> 0, so the bit order is the value order) */
     double thr[RT_WAVE];                  /* distance beyond which nothing can change the ray's result */
     int32_t best_pos[RT_WAVE];            /* lowest triangle position among those with that t */
-    int32_t anyhit[RT_WAVE];              /* the caller only asks whether something is hit before tmax */
     int32_t mark[RT_WAVE];                /* triangle step: slot -> leaf item that starts there, or -1 */
     int32_t ex[RT_WAVE];                  /* triangle step: first slot of each leaf item */
     uint2 leaf[RT_LEAF_CAP];              /* leaf items: x = first triangle, y = count | lane << 26 */
@@ -380,12 +376,11 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
         w->ray[3][lane] = u.x; w->ray[4][lane] = u.y; w->ray[5][lane] = u.z;
         w->ray[6][lane] = k.iu.x; w->ray[7][lane] = k.iu.y; w->ray[8][lane] = k.iu.z;
         w->ray[9][lane] = k.nc.x; w->ray[10][lane] = k.nc.y; w->ray[11][lane] = k.nc.z;
-        w->tol[lane] = k.tol;
+        w->tol[lane] = (anyhit && prune) ? -k.tol : k.tol; /* the sign bit of a NaN is kept too */
     }
     w->best_t[lane] = (unsigned long long)__double_as_longlong(t0);
     w->best_pos[lane] = INT32_MAX;
     w->thr[lane] = prune ? t0 * RT_PRUNE_SLACK : __builtin_huge_val();
-    w->anyhit[lane] = (anyhit && prune) ? 1 : 0;
 
     int n_nodes = 0, n_leaves = 0; /* wave-uniform stack heights */
     int mi = 0;
@@ -398,7 +393,7 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
             RayK k;
             k.iu = mk(w->ray[6][lane], w->ray[7][lane], w->ray[8][lane]);
             k.nc = mk(w->ray[9][lane], w->ray[10][lane], w->ray[11][lane]);
-            k.tol = w->tol[lane];
+            k.tol = fabs(w->tol[lane]);
             const double my_thr = w->thr[lane];
             do {
                 const RootRec &m = roots[mi];
@@ -408,9 +403,9 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
                 if (active) {
                     if (CNT) cnt.box_tests++;
                     bool unsure;
-                    box_fast(ldbox(m.box), k, pass, unsure, tn);
+                    box_fast(Box6{(double)m.box[0], (double)m.box[1], (double)m.box[2], (double)m.box[3], (double)m.box[4], (double)m.box[5]}, k, pass, unsure, tn);
                     if (__builtin_expect(unsure, 0)) {
-                        pass = box_hit_exact(m.box, C.x, C.y, C.z, u.x, u.y, u.z);
+                        pass = box_hit_exact(sc.meshes[mi - 1].root_box, C.x, C.y, C.z, u.x, u.y, u.z);
                         tn = -__builtin_huge_val();
                     }
                     if (CNT && pass) cnt.mesh_calls++;
@@ -482,7 +477,7 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
                     atomicOr(sc.overflow, 2);
                     ok = false;
                 }
-                /* all nine coordinate loads and the ray's LDS reads are issued before anything is waited for:
+                /* all coordinate loads and the ray's LDS reads are issued before anything is waited for:
                  * unconditional (a lane without a triangle reads triangle 0), fenced, then pinned */
                 Tri3 tv = tri_load(sc, ok ? tri : 0u);
                 V3 rc = mk(w->ray[0][rl], w->ray[1][rl], w->ray[2][rl]);
@@ -512,7 +507,7 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
                         mine = (tb == cur);
                         if (mine && old > cur) { /* this lane lowered the minimum */
                             w->best_pos[rl] = INT32_MAX;
-                            if (prune) w->thr[rl] = w->anyhit[rl] ? 0.0 : lt * RT_PRUNE_SLACK;
+                            if (prune) w->thr[rl] = (__double_as_longlong(w->tol[rl]) < 0) ? 0.0 : lt * RT_PRUNE_SLACK;
                         }
                     }
                     wave_sync();
@@ -547,7 +542,7 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
                 RayK rk;
                 rk.iu = mk(w->ray[6][rl], w->ray[7][rl], w->ray[8][rl]);
                 rk.nc = mk(w->ray[9][rl], w->ray[10][rl], w->ray[11][rl]);
-                rk.tol = w->tol[rl];
+                rk.tol = fabs(w->tol[rl]);
                 have = have && !((double)__uint_as_float(it.y) > thr); /* fallen behind the threshold since it was pushed */
                 if (CNT && have) { cnt.nodes++; cnt.box_tests += 2; }
                 int32_t L = __float_as_int(q3.x), R = __float_as_int(q3.y);
@@ -605,7 +600,7 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
         const double tm = __longlong_as_double((long long)w->best_t[lane]);
         const int32_t pos = w->best_pos[lane];
         if (pos != INT32_MAX) {
-            const int32_t mi2 = sc.tri_mesh[pos];
+            const int32_t mi2 = sc.tris[pos].mesh;
             const int32_t oid = sc.meshes[mi2].object_id;
             if (tm < h.t || (tm == h.t && oid < h.obj)) {
                 h.t = tm; h.obj = oid; h.prim = pos; h.mesh = mi2;
