@@ -40,10 +40,11 @@ def algorithmic_flops(c, n_spheres):
     return flops, transc
 
 
-def algorithmic_bytes(c):
-    """FP64 layout: 128 B per BVH record visited, 80 B per triangle tested, 128 B of attributes per
-    mesh hit (upper bound: one per mesh call), 24 B accumulate per path."""
-    return c["nodes"] * 128 + c["tris"] * 80 + c["mesh_calls"] * 128 + c["paths"] * 24
+def algorithmic_bytes(c, node_bytes=128):
+    """node_bytes per BVH record visited (128 B = two FP64 boxes + child links, what the algorithm as the
+    reference states it reads; the kernel's own records are 64 B with float boxes), 80 B per triangle
+    tested, 128 B of attributes per mesh hit (upper bound: one per mesh call), 24 B accumulate per path."""
+    return c["nodes"] * node_bytes + c["tris"] * 80 + c["mesh_calls"] * 128 + c["paths"] * 24
 
 
 def main():
@@ -153,7 +154,7 @@ def main():
         flops_per_path = flops / c["paths"]
         bytes_per_path = algorithmic_bytes(c) / c["paths"]
         gpu_flops_per_path = algorithmic_flops(g, info["n_spheres"])[0] / g["paths"]
-        gpu_bytes_per_path = algorithmic_bytes(g) / g["paths"]
+        gpu_bytes_per_path = algorithmic_bytes(g, node_bytes=64) / g["paths"]
         paths_per_launch = float(W) * H * args.spp_step * args.steps / max(1, kernel_launches)
         avg_launch_s = kernel_ms / 1e3 / max(1, kernel_launches)
         achieved_tflops = flops_per_path * paths_per_launch / avg_launch_s / 1e12

@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_intersect_kernel(DScene sc, const
     bool ok = scene_closest_wave<false>(sc, w, sph, roots, live, C, u, 1E10, false, prune != 0, h, cnt);
     if (!live) return;
     obj_id[q] = ok ? h.obj : -1;
-    tri_id[q] = (ok && h.mesh >= 0) ? sc.tris[h.prim].orig_id : -1;
+    tri_id[q] = (ok && h.mesh >= 0 && h.prim >= 0) ? sc.tris[h.prim].orig_id : -1;
     t[q] = h.t;
     Surf s;
     s.P = s.N = s.albedo = mk(0, 0, 0);
@@ -824,6 +824,15 @@ int rt_debug_stats(rt_ctx *c, uint64_t *out20) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(out20, reinterpret_cast<uint64_t *>(c->d_counters) + 8, 20 * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+/* not part of the public header: workgroups of the render kernel that fit one CU with the current scene's LDS use (tools/ only) */
+int rt_debug_occupancy(rt_ctx *c, int *blocks_per_cu, int *lds_bytes) {
+    if (!c || !blocks_per_cu || !lds_bytes || !c->have_scene) return RT_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, rt_render_kernel<false>, RT_BLOCK, c->lds_bytes));
+    *lds_bytes = (int)c->lds_bytes;
     return RT_OK;
 }
 

@@ -45,6 +45,7 @@ namespace rtd {
 #define RT_LEAF_TRIGGER 24        /* pending leaf items that make the next pool step a triangle step */
 #define RT_NODE_BITS 26           /* node index bits in a node item (the ray lane takes the top 6) */
 #define RT_MAX_DEPTH 60
+#define RT_PHANTOM_BASE (1 << 30)  /* best_pos values from here on: "mesh (value - base) reports a hit without a triangle" */
 
 /* what the root phase needs of a mesh: the root box (raytracer.cpp:644) and where the tree starts */
 struct RootRec { /* 32 bytes; the box rounded to float like NodeRec32, the double box stays in rt_mesh */
@@ -380,7 +381,9 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
     }
     w->best_t[lane] = (unsigned long long)__double_as_longlong(t0);
     w->best_pos[lane] = INT32_MAX;
-    w->thr[lane] = prune ? t0 * RT_PRUNE_SLACK : __builtin_huge_val();
+    /* While nothing closer than 1E9 is known, nothing may be skipped by distance: a triangle hit at or beyond
+     * 1E9 still makes TriangleMesh::intersect return true (raytracer.cpp:689 sets has_inter before :690 compares). */
+    w->thr[lane] = (prune && t0 < 1E9) ? t0 * RT_PRUNE_SLACK : __builtin_huge_val();
 
     int n_nodes = 0, n_leaves = 0; /* wave-uniform stack heights */
     int mi = 0;
@@ -492,6 +495,12 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
                 if (ok) {
                     if (CNT) cnt.tris++;
                     acc = tri_eval(tv, rc, ru, beta, gamma, lt);
+                    if (__builtin_expect(acc && !(lt < 1E9), 0)) {
+                        /* raytracer.cpp:689-690: has_inter is set, t stays 1E9 and P, N, colour stay as the caller
+                         * initialised them. Remembered as the lowest such mesh; any triangle below 1E9 overrides it. */
+                        acc = false;
+                        atomicMin(&w->best_pos[rl], RT_PHANTOM_BASE + sc.tris[tri].mesh);
+                    }
                 }
                 if (__ballot(acc) != 0ull) {
                     /* keep (min t, then min position) per ray. LDS executes one wave's instructions in
@@ -600,12 +609,14 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
         const double tm = __longlong_as_double((long long)w->best_t[lane]);
         const int32_t pos = w->best_pos[lane];
         if (pos != INT32_MAX) {
-            const int32_t mi2 = sc.tris[pos].mesh;
+            const bool phantom = pos >= RT_PHANTOM_BASE; /* the mesh reported a hit at t = 1E9 without a triangle */
+            const int32_t mi2 = phantom ? pos - RT_PHANTOM_BASE : sc.tris[pos].mesh;
+            const double tmm = phantom ? 1E9 : tm;
             const int32_t oid = sc.meshes[mi2].object_id;
-            if (tm < h.t || (tm == h.t && oid < h.obj)) {
-                h.t = tm; h.obj = oid; h.prim = pos; h.mesh = mi2;
+            if (tmm < h.t || (tmm == h.t && oid < h.obj)) {
+                h.t = tmm; h.obj = oid; h.prim = phantom ? -1 : pos; h.mesh = mi2;
                 double lt;
-                (void)tri_test(sc, (uint32_t)pos, C, u, h.beta, h.gamma, lt); /* alpha, beta, gamma of the winner (:683-685) */
+                if (!phantom) (void)tri_test(sc, (uint32_t)pos, C, u, h.beta, h.gamma, lt); /* alpha, beta, gamma of the winner (:683-685) */
             }
         }
     }
@@ -627,6 +638,9 @@ __device__ __forceinline__ void hit_surface(const DScene &sc, const rt_sphere *s
         s.N = unit(sub(s.P, O));
         s.albedo = ld3(sph[h.prim].albedo);
         s.flags = sph[h.prim].flags;
+    } else if (h.prim < 0) { /* a mesh hit without a triangle: Scene::intersect's zero-initialised locals (:936) */
+        s.P = s.N = s.albedo = mk(0, 0, 0);
+        s.flags = sc.meshes[h.mesh].flags;
     } else { /* TriangleMesh::intersect :693-720 */
         const rt_mesh &m = sc.meshes[h.mesh];
         const rt_tri_attr *at = sc.attrs + h.prim;

@@ -70,6 +70,21 @@ def chain_mesh(name):
     return scenes.blob_mesh(20, size=(0.3 + 0.1 * seed, 0.6, 0.72), offset=(0.0, 0.0, 0.72), seed=seed)
 
 
+def far_scene():
+    """an unbounded scene whose mesh can only be hit beyond t = 1E9: TriangleMesh::intersect then returns true
+    with t = 1E9 and leaves P, N and the colour as Scene::intersect zero-initialised them (raytracer.cpp:689-690, :936)"""
+    off, size = 1e36, 1e35
+    v, n, uv, ix = scenes.blob_mesh(8, size=(size, size, size), offset=(off, off, off), seed=3)
+    objs = [dict(kind="sphere", O=(off, off, off + 3 * size), R=0.25 * size, albedo=(1, 1, 1), mirror=False, transp=False),
+            dict(kind="mesh", verts=v, normals=n, uvs=uv, idx=ix, albedo=(1, 1, 1), mirror=False, transp=False)]
+    u = scenes._hash01(np.arange(6 * 600), 21).reshape(600, 6)
+    org = u[:, :3] * 2 - 1
+    org = off + 4 * size * org / np.sqrt((org * org).sum(1))[:, None]
+    d = off + (u[:, 3:] * 1.6 - 0.8) * size - org
+    d /= np.sqrt((d * d).sum(1))[:, None]
+    return objs, np.ascontiguousarray(np.concatenate([org, d], 1))
+
+
 def main():
     assert ob.have_trueref(), "oracle/_ref/libref_true.so missing: run `make -C oracle` where /root/reference exists"
     out = {}
@@ -102,6 +117,14 @@ def main():
             out["%s_bvh_%d" % (name, oid)] = np.array([len(boxes), int(dfl[:, 2].sum())])
             out["%s_bvhhash_%d" % (name, oid)] = np.array([sha(boxes), sha(dfl), sha(perm)])
         print(name, "hits on meshes:", int((hp["tri"] >= 0).sum()), "/", len(rays), " random:", int((hr["tri"] >= 0).sum()))
+    # a hit reported without a triangle (raytracer.cpp:689-690)
+    objs, rays = far_scene()
+    hf = ob.TrueRefScene(objs, 1.0, (0, 0, 0)).intersect_rays(rays)
+    out["far_obj"] = hf["obj"].astype(np.int16)
+    out["far_t"] = hf["t"]
+    out["far_no_tri"] = hf["tri"] < 0
+    out["far_PNalbedo"] = np.concatenate([hf["P"], hf["N"], hf["albedo"]], 1)
+    print("far scene: hits without a triangle:", int(((hf["obj"] == 1) & (hf["tri"] < 0)).sum()), "/", len(rays))
     # tone map (raytracer.cpp:1488-1501) on a value ramp + specials
     acc = (scenes._hash01(np.arange(64 * 64 * 3), 3).reshape(64, 64, 3) ** 4) * 4e5
     acc[0, 0] = (np.nan, -1.0, 0.0)

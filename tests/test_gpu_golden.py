@@ -59,6 +59,27 @@ def test_reference_sample_radiance(gpu, rta, scenes, name):
     assert (rel > 1e-9).sum() <= max(3, rel.size // 3000), np.sort(rel.ravel())[-6:]
 
 
+def test_hit_without_triangle(gpu, rta, scenes):
+    """a triangle met at or beyond t = 1E9 makes the mesh report a hit at 1E9 with zeroed P, N and colour (raytracer.cpp:689-690)"""
+    mg = importlib.import_module("tests.golden.make_golden")
+    objs, rays = mg.far_scene()
+    s = rta.Scene(I=1.0, L=(0.0, 0.0, 0.0))
+    s.add(rta.Sphere(objs[0]["O"], objs[0]["R"], objs[0]["albedo"]))
+    m = rta.TriangleMesh(objs[1]["albedo"])
+    m.set_raw(objs[1]["verts"], objs[1]["normals"], objs[1]["uvs"], objs[1]["idx"])
+    m.buildBVH()
+    s.add(m)
+    gpu.upload(s)
+    for prune in (1, 0):
+        rta.lib.rt_debug_probe_prune(gpu._h, prune)
+        h = gpu.intersect_rays(rays)
+        assert np.array_equal(h["obj"], GOLD["far_obj"])
+        assert np.array_equal(h["t"], GOLD["far_t"])
+        assert np.array_equal(h["tri"] < 0, GOLD["far_no_tri"])
+        assert np.array_equal(np.concatenate([h["P"], h["N"], h["albedo"]], 1), GOLD["far_PNalbedo"], equal_nan=True)
+    rta.lib.rt_debug_probe_prune(gpu._h, 1)
+
+
 def test_resolve_matches_reference(gpu, rta, scenes):
     acc = (scenes._hash01(np.arange(64 * 64 * 3), 3).reshape(64, 64, 3) ** 4) * 4e5
     acc[0, 0] = (np.nan, -1.0, 0.0)

@@ -102,6 +102,91 @@ def test_degenerate_rays(gpu, rta, scenes, ob, probe_mode):
     assert gpu.intersect_rays(np.empty((0, 6)))["obj"].shape == (0,)
 
 
+def test_rays_through_box_corners(gpu, rta, scenes, ob, probe_mode):
+    """Rays aimed exactly at corners, edge midpoints and face centres of BVH boxes: tMax and tMin of the
+    slab test (nearly) coincide, which is where the fast box test must hand over to the true divisions."""
+    s, cam, flags, orc = _scene_pair(ob, scenes, scenes.mesh_room, W=64, n_tris=6000, tex_size=32)
+    gpu.upload(s)
+    mesh = [o for o in s.objects if isinstance(o, rta.TriangleMesh)][0]
+    boxes, dfl = mesh.bvh_dump()
+    sel = boxes[:: max(1, len(boxes) // 700)]
+    lo, hi = sel[:, :3], sel[:, 3:]
+    mid = (lo + hi) / 2
+    targets = []
+    for cx in (lo[:, 0], mid[:, 0], hi[:, 0]):
+        for cy in (lo[:, 1], mid[:, 1], hi[:, 1]):
+            for cz in (lo[:, 2], mid[:, 2], hi[:, 2]):
+                targets.append(np.stack([cx, cy, cz], 1))
+    targets = np.concatenate(targets)
+    rays = []
+    for org in ((0.0, 30.0, 55.0), (-20.0, 3.0, 10.0), (5.0, 45.0, -30.0)):
+        d = targets - np.array(org)
+        d = d / np.sqrt((d * d).sum(1))[:, None]
+        rays.append(np.concatenate([np.broadcast_to(org, d.shape), d], 1))
+    # rays inside a face plane of a box (one slab interval collapses) and along box edges
+    d = hi - lo
+    ok = np.sqrt((d * d).sum(1)) > 0
+    along = d[ok] / np.sqrt((d[ok] * d[ok]).sum(1))[:, None]
+    rays.append(np.concatenate([lo[ok] - 3 * along, along], 1))
+    flat = along.copy(); flat[:, 1] = 0
+    okf = np.sqrt((flat * flat).sum(1)) > 0
+    flat = flat[okf] / np.sqrt((flat[okf] * flat[okf]).sum(1))[:, None]
+    rays.append(np.concatenate([lo[ok][okf] - 2 * flat, flat], 1))
+    rays = np.ascontiguousarray(np.concatenate(rays))
+    g, o = gpu.intersect_rays(rays), orc.intersect_rays(rays)
+    assert (o["tri"] >= 0).sum() > 1000
+    _check_hits(g, o)
+
+
+def test_coarse_float_boxes(gpu, rta, scenes, ob, probe_mode):
+    """A small mesh far from the origin: near 1e8 a float resolves steps of 8, coarser than the boxes, so
+    the float copies decide almost nothing and the decisions come from the double boxes. Farther out
+    (1e36: beyond the float range) nothing can be hit below the reference's t limits (1E9, 1E10); the
+    answer must be "no hit" for every ray, without NaNs."""
+    for off, size, expect_hits in ((1e8, 40.0, True), (1e36, 1e35, False)):
+        v, n, uv, ix = scenes.blob_mesh(8, size=(size, size, size), offset=(off, off, off), seed=3)
+        s = rta.Scene(I=1.0, L=(0.0, 0.0, 0.0))
+        s.add(rta.Sphere((off, off, off + 3 * size), 0.25 * size, (1, 1, 1)))
+        m = rta.TriangleMesh((1, 1, 1))
+        m.set_raw(v, n, uv, ix)
+        m.buildBVH()
+        s.add(m)
+        orc = ob.OracleScene(scenes.export_objects(s), s.I, s.L)
+        gpu.upload(s)
+        rng = np.random.default_rng(11)
+        nr = 4000
+        org = rng.normal(size=(nr, 3)); org = off + 4 * size * org / np.sqrt((org * org).sum(1))[:, None]
+        tgt = off + rng.uniform(-0.8, 0.8, (nr, 3)) * size
+        d = tgt - org
+        d /= np.sqrt((d * d).sum(1))[:, None]
+        rays = np.ascontiguousarray(np.concatenate([org, d], 1))
+        g, o = gpu.intersect_rays(rays), orc.intersect_rays(rays)
+        if expect_hits:
+            assert (o["tri"] >= 0).sum() > 1000
+        else:
+            assert (o["tri"] >= 0).sum() == 0
+        _check_hits(g, o)
+
+
+def test_converged_image_rmse(gpu, rta, scenes, ob):
+    """Independent noise: the GPU image at 256 spp (seed 10) against the oracle image at 256 spp with another
+    seed, both tone-mapped. The two only share the scene and the estimator, so the RMSE measures bias; the
+    bar is 2 grey levels of 255 for the mean signed difference and an RMSE no worse than oracle-vs-oracle
+    with two seeds (noise floor) times 1.25."""
+    W, spp = 48, 256
+    s, cam, flags, orc = _scene_pair(ob, scenes, scenes.mesh_room, W=W, n_tris=4000, tex_size=32)
+    gpu.upload(s)
+    gpu.accum_clear(W, W)
+    gpu.render(cam, rta.make_params(W, W, spp, seed=10, flags=flags))
+    g = gpu.resolve(W, W, spp).astype(np.float64)
+    o1 = ob.resolve(orc.render(cam, rta.make_params(W, W, spp, seed=77, flags=flags)), spp).astype(np.float64)
+    o2 = ob.resolve(orc.render(cam, rta.make_params(W, W, spp, seed=78, flags=flags)), spp).astype(np.float64)
+    floor = np.sqrt(((o1 - o2) ** 2).mean())
+    rmse = np.sqrt(((g - o1) ** 2).mean())
+    assert abs((g - o1).mean()) < 2.0, (g - o1).mean()
+    assert rmse < 1.25 * floor + 0.5, (rmse, floor)
+
+
 def test_deterministic_room_radiance(gpu, rta, scenes, ob):
     """cfg1 at reduced size: noise-off path (point light, hard shadows, mirror, refraction), 1 spp"""
     W = 128

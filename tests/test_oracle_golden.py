@@ -79,6 +79,21 @@ def test_bvh_matches_reference(rta, scenes, ob, name):
         assert sha(boxes) == hb and sha(dfl) == hd and sha(info["perm"]) == hp
 
 
+def _check_far(h):
+    assert np.array_equal(h["obj"], GOLD["far_obj"])
+    assert np.array_equal(h["t"], GOLD["far_t"])
+    assert np.array_equal(h["tri"] < 0, GOLD["far_no_tri"])
+    assert np.array_equal(np.concatenate([h["P"], h["N"], h["albedo"]], 1), GOLD["far_PNalbedo"], equal_nan=True)
+    assert ((h["obj"] == 1) & (h["tri"] < 0) & (h["t"] == 1e9)).sum() > 300
+
+
+def test_hit_without_triangle(scenes, ob):
+    """a triangle met at or beyond t = 1E9 makes the mesh report a hit at 1E9 with zeroed P, N and colour (raytracer.cpp:689-690)"""
+    import importlib
+    objs, rays = importlib.import_module("tests.golden.make_golden").far_scene()
+    _check_far(ob.OracleScene(objs, 1.0, (0, 0, 0)).intersect_rays(rays))
+
+
 def test_resolve(scenes, ob):
     acc = (scenes._hash01(np.arange(64 * 64 * 3), 3).reshape(64, 64, 3) ** 4) * 4e5
     acc[0, 0] = (np.nan, -1.0, 0.0)

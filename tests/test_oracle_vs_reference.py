@@ -64,6 +64,18 @@ def test_axis_aligned_normals_like_the_reference(rta, scenes, ob):
     assert lit >= 2
 
 
+def test_hit_without_triangle_beyond_1e9(scenes, ob):
+    """an unbounded scene whose mesh can only be hit beyond t = 1E9 (raytracer.cpp:689-690, :936)"""
+    import importlib
+    objs, rays = importlib.import_module("tests.golden.make_golden").far_scene()
+    o, t = ob.OracleScene(objs, 1.0, (0, 0, 0)), ob.TrueRefScene(objs, 1.0, (0, 0, 0))
+    a, b = o.intersect_rays(rays), t.intersect_rays(rays)
+    assert ((b["obj"] == 1) & (b["tri"] < 0) & (b["t"] == 1e9)).sum() > 300
+    for k in ("obj", "t", "P", "N", "albedo"):  # the harness has no triangle to name here (it reports "none found")
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    assert ((a["tri"] < 0) == (b["tri"] < 0)).all()
+
+
 @pytest.mark.skipif(not os.path.isdir(REF_OBJECTS), reason="reference assets absent")
 def test_real_obj_with_stb_texture(rta, scenes, ob):
     """the rifle soldier as the reference loads it (readOBJ + stb_image JPEG decode + the battle-scene transform
