@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP64_VECTOR_TFLOPS = 78.6   # MI355X vector FP64 = half the 157.3 TFLOP/s FP32 vector peak
 PEAK_HBM_GBS = 8000.0
+PROFILE_PREFIX = "r1_v5_float_records_"  # rocprofv3 summaries of this round's kernel under profiles/
 
 
 def algorithmic_flops(c, n_spheres):
@@ -171,6 +172,18 @@ def main():
                                      "flops_per_path": round(gpu_flops_per_path, 1), "bytes_per_path": round(gpu_bytes_per_path, 1),
                                      "TFLOPs": round(gpu_flops_per_path * paths_per_launch / avg_launch_s / 1e12, 4),
                                      "GBs": round(gpu_bytes_per_path * paths_per_launch / avg_launch_s / 1e9, 2)}}
+        # HBM-side bytes per launch: not collectable inside this process (PMC needs rocprofv3 around it); taken from the
+        # committed counter pass of this same command, FETCH_SIZE (KB, 64 B per L2 fabric read request) doubled as the
+        # gfx950 correction for 128-byte requests prescribes. Null when the summary is absent.
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", PROFILE_PREFIX + "mem2.json")))
+            kk = [k for k in pm if "rt_render_kernel<false>" in k][0]
+            roofline["traffic"] = round(pm[kk]["FETCH_SIZE"] * 1024.0 * 2.0 / pm[kk]["dispatches"], 1)
+            roofline["traffic_note"] = ("bytes per launch of 1024x1024x16 paths from profiles/%smem2.json (rocprofv3 --pmc FETCH_SIZE of "
+                                        "`bench.py --steps 2 --warmup 1 --spp-step 16`), x2 gfx950 correction; algorithmic bytes per launch = %.4g"
+                                        % (PROFILE_PREFIX, bytes_per_path * paths_per_launch))
+        except (OSError, KeyError, IndexError, ValueError, ZeroDivisionError):
+            pass
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import bindings as ob

@@ -45,6 +45,8 @@ namespace rtd {
 #define RT_LEAF_TRIGGER 24        /* pending leaf items that make the next pool step a triangle step */
 #define RT_NODE_BITS 26           /* node index bits in a node item (the ray lane takes the top 6) */
 #define RT_MAX_DEPTH 60
+static_assert(RT_FEED_BELOW + RT_WAVE <= RT_NODE_SOFT, "a fed mesh adds up to 64 node items on top of RT_FEED_BELOW - 1");
+static_assert(RT_LEAF_CAP >= 3 * RT_WAVE, "a node step adds up to 128 leaf items and runs only when 128 slots are free; a fed mesh adds up to 64 on top of 64");
 #define RT_PHANTOM_BASE (1 << 30)  /* best_pos values from here on: "mesh (value - base) reports a hit without a triangle" */
 
 /* what the root phase needs of a mesh: the root box (raytracer.cpp:644) and where the tree starts */

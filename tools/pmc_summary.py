@@ -4,13 +4,17 @@ import collections, csv, glob, json, os, sys
 d = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/prof/pmc1'
 f = max(glob.glob(os.path.join(d, '**', '*_counter_collection.csv'), recursive=True), key=os.path.getmtime)
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
+disp = collections.defaultdict(set)
 for r in csv.DictReader(open(f)):
-    agg[r['Kernel_Name'].split('(')[0]][r['Counter_Name']] += float(r['Counter_Value'])
+    k = r['Kernel_Name'].split('(')[0]
+    agg[k][r['Counter_Name']] += float(r['Counter_Value'])
+    disp[k].add(r.get('Dispatch_Id', r.get('Correlation_Id', '')))
 out = {}
 for k, v in agg.items():
     if 'rt_' not in k:
         continue
     v = dict(v)
+    v['dispatches'] = len(disp[k])
     if 'SQ_ACTIVE_INST_VALU' in v and 'SQ_THREAD_CYCLES_VALU' in v:
         v['valu_lane_utilization'] = v['SQ_THREAD_CYCLES_VALU'] / (v['SQ_ACTIVE_INST_VALU'] * 64)
     if 'SQ_WAVE_CYCLES' in v:
