@@ -35,14 +35,18 @@ namespace rtd {
 #define RT_WAVE 64
 #define RT_LDS_SPHERES_MAX 64     /* sphere lists up to this size are staged in LDS */
 #define RT_LDS_ROOTS_MAX 32       /* mesh root records (box + root) up to this many are staged in LDS */
-#define RT_FEED_BELOW 64          /* mesh roots are fed to the pool while fewer node items than this are pending */
+#ifndef RT_FEED_BELOW
+#define RT_FEED_BELOW 448         /* mesh roots are fed to the pool while fewer node items than this are pending (measured: the more the better) */
+#endif
 #ifndef RT_NODE_SOFT
 #define RT_NODE_SOFT 512
 #endif          /* node-item stack height up to which 64 items are popped per step */
 #ifndef RT_LEAF_CAP
 #define RT_LEAF_CAP 256           /* leaf-item stack entries */
 #endif
-#define RT_LEAF_TRIGGER 24        /* pending leaf items that make the next pool step a triangle step */
+#ifndef RT_LEAF_TRIGGER
+#define RT_LEAF_TRIGGER 64        /* pending leaf items that make the next pool step a triangle step */
+#endif
 #define RT_NODE_BITS 26           /* node index bits in a node item (the ray lane takes the top 6) */
 #define RT_MAX_DEPTH 60
 static_assert(RT_FEED_BELOW + RT_WAVE <= RT_NODE_SOFT, "a fed mesh adds up to 64 node items on top of RT_FEED_BELOW - 1");
