@@ -58,7 +58,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=12, help="samples per pixel of the CPU baseline's bounded sample (12 spp = about 15 s on 16 cores)")
     ap.add_argument("--out-png", default="")
-    ap.add_argument("--mode", default="default", choices=["default", "wavefront"], help="A/B switch: two-kernel wavefront render loop instead of the single persistent kernel")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -84,8 +83,6 @@ def main():
     W = H = args.size
     t0 = time.time()
     scene, cam, flags, meta = scenes.battle(W=W)
-    if args.mode == "wavefront":
-        flags |= rta.RT_F_WAVEFRONT
     r = rta.Renderer(local_rank)
     r.upload(scene)
     info = scene.flat_info()

@@ -162,8 +162,6 @@ typedef struct rt_camera {
 #define RT_F_NO_FRESNEL 4u  /* dielectric always refracts unless total reflection (raytracer.cpp:1033) */
 #define RT_F_NO_JITTER 8u   /* camera ray Ray(C,u) through the pixel centre (raytracer.cpp:1482), no RNG draws */
 #define RT_F_COUNTERS 16u   /* accumulate rt_counters (slower) */
-#define RT_F_WAVEFRONT 64u  /* two-kernel form of the render loop (traverse / shade kernels over compacted queues in HBM) instead of the
-                               single persistent kernel; same results, measured 2x slower on the battle scene */
 #define RT_F_NO_PRUNE 32u   /* visit every BVH node whose box the ray's line crosses, as TriangleMesh::intersect does (raytracer.cpp:652-666);
                                default: skip boxes that start behind the closest hit found so far (same results) */
 

@@ -26,7 +26,7 @@ lib = C.CDLL(LIB_PATH)
 
 # --- PODs of include/rt_amd.h --------------------------------------------------------------------
 RT_MAT_MIRROR, RT_MAT_TRANSPARENT = 1, 2
-RT_F_POINT_LIGHT, RT_F_NO_INDIRECT, RT_F_NO_FRESNEL, RT_F_NO_JITTER, RT_F_COUNTERS, RT_F_NO_PRUNE, RT_F_WAVEFRONT = 1, 2, 4, 8, 16, 32, 64
+RT_F_POINT_LIGHT, RT_F_NO_INDIRECT, RT_F_NO_FRESNEL, RT_F_NO_JITTER, RT_F_COUNTERS, RT_F_NO_PRUNE = 1, 2, 4, 8, 16, 32
 
 
 class rt_camera(C.Structure):

@@ -97,7 +97,10 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_intersect_kernel(DScene sc, const
     if (live) { C = ld3(rays + 6 * q); u = ld3(rays + 6 * q + 3); }
     HitRec h;
     Cnt cnt = {};
-    bool ok = scene_closest_wave<false>(sc, w, sph, roots, live, C, u, 1E10, false, prune != 0, h, cnt);
+    HitRec h2;
+    const RayQ qa = RayQ{live, C, u, 1E10, false}, qb = RayQ{false, C, u, 1E10, false};
+    scene_closest_wave<false>(sc, w, sph, roots, qa, qb, prune != 0, h, h2, cnt);
+    const bool ok = h.obj != INT32_MAX;
     if (!live) return;
     obj_id[q] = ok ? h.obj : -1;
     tri_id[q] = (ok && h.mesh >= 0 && h.prim >= 0) ? sc.tris[h.prim].orig_id : -1;
@@ -109,141 +112,6 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_intersect_kernel(DScene sc, const
     PN[6 * q] = s.P.x; PN[6 * q + 1] = s.P.y; PN[6 * q + 2] = s.P.z;
     PN[6 * q + 3] = s.N.x; PN[6 * q + 4] = s.N.y; PN[6 * q + 5] = s.N.z;
     albedo[3 * q] = s.albedo.x; albedo[3 * q + 1] = s.albedo.y; albedo[3 * q + 2] = s.albedo.z;
-}
-
-/* ---------------------------------------------------------------------------------------------
- * wavefront form of the render loop: the per-pixel state machine of trace_pixel with its state in
- * HBM and its loop body split into two kernels, so that the traversal kernel carries no shading
- * registers (more waves per SIMD to hide the latency of BVH fetches) and every lane of a traversal
- * wave has a ray (the queue of unfinished pixels is compacted every round).
- *   round:  rt_wf_traverse  - one wave per 64 queue entries: closest hit of each pixel's current ray
- *           rt_wf_shade     - one lane per queue entry: path_advance + path_fresh, next queue
- * A pixel (slot) is owned by one lane at a time and its samples are added in order, so the result does
- * not depend on how the queues are ordered.
- * ------------------------------------------------------------------------------------------- */
-#define WF_ND 28 /* doubles per slot: rC ru T Lsum acc nee nextC nextU vAlbedo (3 each) + sh_limit */
-#define WF_NU 5  /* uint32 per slot: key lo, key hi, ctr, k, rebond | flags << 16 */
-
-struct WfBuf {
-    double *d;      /* [WF_ND][n] */
-    uint32_t *u;    /* [WF_NU][n] */
-    double *hd;     /* hit: t, beta, gamma  [3][n] */
-    int32_t *hi;    /* hit: obj, prim, mesh [3][n] */
-    int32_t *queue[2];
-    int32_t *count; /* [2] */
-    int64_t n;
-};
-
-__device__ __forceinline__ void wf_store3(double *d, int64_t n, int64_t s, int f, V3 v) {
-    d[(int64_t)f * n + s] = v.x; d[(int64_t)(f + 1) * n + s] = v.y; d[(int64_t)(f + 2) * n + s] = v.z;
-}
-__device__ __forceinline__ V3 wf_load3(const double *d, int64_t n, int64_t s, int f) {
-    return mk(d[(int64_t)f * n + s], d[(int64_t)(f + 1) * n + s], d[(int64_t)(f + 2) * n + s]);
-}
-__device__ __forceinline__ void wf_store(const WfBuf &b, int64_t s, const Path &q) {
-    wf_store3(b.d, b.n, s, 0, q.rC); wf_store3(b.d, b.n, s, 3, q.ru); wf_store3(b.d, b.n, s, 6, q.T);
-    wf_store3(b.d, b.n, s, 9, q.Lsum); wf_store3(b.d, b.n, s, 12, q.acc); wf_store3(b.d, b.n, s, 15, q.nee);
-    wf_store3(b.d, b.n, s, 18, q.nextC); wf_store3(b.d, b.n, s, 21, q.nextU); wf_store3(b.d, b.n, s, 24, q.vAlbedo);
-    b.d[27 * b.n + s] = q.sh_limit;
-    b.u[s] = (uint32_t)q.key; b.u[b.n + s] = (uint32_t)(q.key >> 32); b.u[2 * b.n + s] = q.ctr; b.u[3 * b.n + s] = (uint32_t)q.k;
-    b.u[4 * b.n + s] = (uint32_t)q.rebond | (q.lastDiffuse ? 1u << 16 : 0u) | (q.shadow ? 1u << 17 : 0u) | (q.fresh ? 1u << 18 : 0u) |
-                       (q.finished ? 1u << 19 : 0u);
-}
-__device__ __forceinline__ void wf_load(const WfBuf &b, int64_t s, Path &q) {
-    q.rC = wf_load3(b.d, b.n, s, 0); q.ru = wf_load3(b.d, b.n, s, 3); q.T = wf_load3(b.d, b.n, s, 6);
-    q.Lsum = wf_load3(b.d, b.n, s, 9); q.acc = wf_load3(b.d, b.n, s, 12); q.nee = wf_load3(b.d, b.n, s, 15);
-    q.nextC = wf_load3(b.d, b.n, s, 18); q.nextU = wf_load3(b.d, b.n, s, 21); q.vAlbedo = wf_load3(b.d, b.n, s, 24);
-    q.sh_limit = b.d[27 * b.n + s];
-    q.key = (uint64_t)b.u[s] | ((uint64_t)b.u[b.n + s] << 32); q.ctr = b.u[2 * b.n + s]; q.k = (int32_t)b.u[3 * b.n + s];
-    const uint32_t f = b.u[4 * b.n + s];
-    q.rebond = (int32_t)(f & 0xFFFFu); q.lastDiffuse = f & (1u << 16); q.shadow = f & (1u << 17); q.fresh = f & (1u << 18);
-    q.finished = f & (1u << 19);
-}
-
-__global__ void __launch_bounds__(256) rt_wf_init(WfBuf b, RenderArgs ra, int k0) {
-    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (s >= b.n) return;
-    int i, j;
-    const bool live = slot_pixel(ra, s, i, j);
-    Path q;
-    path_begin(q, k0, live);
-    wf_store(b, s, q);
-    b.queue[0][s] = (int32_t)s;
-    if (s == 0) { b.count[0] = (int32_t)b.n; b.count[1] = 0; }
-}
-
-__global__ void __launch_bounds__(RT_BLOCK) rt_wf_traverse(DScene sc, WfBuf b, int cur, int prune) {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    const int32_t count = b.count[cur];
-    if (blockIdx.x == 0 && threadIdx.x == 0) b.count[1 - cur] = 0; /* filled by this round's shade kernel */
-    const int64_t base = (int64_t)blockIdx.x * RT_BLOCK;
-    if (base >= count) return;
-    const rt_sphere *sph;
-    const RootRec *roots;
-    WaveLDS *w = wave_setup(sc, lds_raw, &sph, &roots);
-    const int64_t idx = base + threadIdx.x;
-    const bool live = idx < count;
-    int64_t s = 0;
-    V3 C = mk(0, 0, 0), u = mk(0, 0, 1);
-    double tmax = 1E10;
-    bool shadow = false;
-    if (live) {
-        s = b.queue[cur][idx];
-        C = wf_load3(b.d, b.n, s, 0);
-        u = wf_load3(b.d, b.n, s, 3);
-        shadow = b.u[4 * b.n + s] & (1u << 17);
-        if (shadow) tmax = b.d[27 * b.n + s];
-    }
-    HitRec h;
-    Cnt cnt = {};
-    (void)scene_closest_wave<false>(sc, w, sph, roots, live, C, u, tmax, shadow, prune != 0, h, cnt);
-    if (live) {
-        b.hd[s] = h.t; b.hd[b.n + s] = h.beta; b.hd[2 * b.n + s] = h.gamma;
-        b.hi[s] = h.obj; b.hi[b.n + s] = h.prim; b.hi[2 * b.n + s] = h.mesh;
-    }
-}
-
-__global__ void __launch_bounds__(256) rt_wf_shade(DScene sc, WfBuf b, RenderArgs ra, int cur, int kend, double *accum) {
-    const int32_t count = b.count[cur];
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    bool cont = false;
-    int64_t s = 0;
-    if (idx < count) {
-        s = b.queue[cur][idx];
-        Path q;
-        wf_load(b, s, q);
-        int i, j;
-        (void)slot_pixel(ra, s, i, j);
-        Cnt cnt = {};
-        if (!q.fresh && !q.finished) {
-            HitRec h;
-            h.t = b.hd[s]; h.beta = b.hd[b.n + s]; h.gamma = b.hd[2 * b.n + s];
-            h.obj = b.hi[s]; h.prim = b.hi[b.n + s]; h.mesh = b.hi[2 * b.n + s];
-            path_advance<false>(sc, sc.spheres, ra, q, h.obj != INT32_MAX, h, cnt);
-        }
-        const bool was_live = !q.finished;
-        path_fresh<false>(ra, q, i, j, kend, cnt);
-        wf_store(b, s, q);
-        if (q.finished) {
-            if (was_live) { /* this pixel's samples are done: one lane adds them (raytracer.cpp:1485) */
-                double *px = accum + ((int64_t)i * ra.p.W + j) * 3;
-                px[0] = px[0] + q.acc.x;
-                px[1] = px[1] + q.acc.y;
-                px[2] = px[2] + q.acc.z;
-            }
-        } else {
-            cont = true;
-        }
-    }
-    /* compact the pixels that go on into the next queue: one atomic per wave */
-    const unsigned long long bal = __ballot(cont);
-    if (bal) {
-        int base = 0;
-        const int lane = threadIdx.x & 63;
-        if (lane == __ffsll((long long)bal) - 1) base = atomicAdd(&b.count[1 - cur], __popcll(bal));
-        base = __shfl(base, __ffsll((long long)bal) - 1, 64);
-        if (cont) b.queue[1 - cur][base + rank_in(bal)] = (int32_t)s;
-    }
 }
 
 /* self-test of the DPP wave scans used by the triangle step */
@@ -292,11 +160,8 @@ struct rt_ctx {
     int *d_overflow = nullptr;
     int *d_next_slot = nullptr;
     int n_cus = 256;
+    int waves_per_cu = 8;
     bool probe_prune = true;
-    /* wavefront state */
-    WfBuf wf{};
-    void *wf_alloc = nullptr;
-    int64_t wf_cap = 0;
 };
 
 static std::string g_create_err;
@@ -389,7 +254,6 @@ void rt_destroy(rt_ctx *c) {
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_overflow) (void)hipFree(c->d_overflow);
     if (c->d_next_slot) (void)hipFree(c->d_next_slot);
-    if (c->wf_alloc) (void)hipFree(c->wf_alloc);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -408,7 +272,7 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
     if ((s->n_spheres && !s->spheres) || (s->n_meshes && !s->meshes) || (s->n_nodes && !s->nodes) ||
         (s->n_tris && (!s->tris || !s->attrs)) || (s->n_tex && (!s->tex || !s->texels)))
         return fail(c, RT_E_INVALID, "rt_upload_scene: NULL array with non-zero count");
-    if (s->n_tris >= (1LL << 26) || s->n_nodes >= (1LL << RT_NODE_BITS)) return fail(c, RT_E_INVALID, "rt_upload_scene: at most 2^26 triangles and BVH records");
+    if (s->n_tris >= (1LL << RT_NODE_BITS) || s->n_nodes >= (1LL << RT_NODE_BITS)) return fail(c, RT_E_INVALID, "rt_upload_scene: at most 2^25 triangles and BVH records");
     if (s->n_meshes > 0 && s->n_tris != (int64_t)s->meshes[s->n_meshes - 1].first_tri + s->meshes[s->n_meshes - 1].n_tris)
         return fail(c, RT_E_INVALID, "rt_upload_scene: n_tris does not match the mesh ranges");
     /* validate everything the kernels index with, so a bad description is an error and not a GPU fault */
@@ -544,6 +408,13 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
     c->lds_bytes = sizeof(WaveLDS) + (size_t)d.node_cap * 8 + 16 + ((s->n_spheres <= RT_LDS_SPHERES_MAX) ? (size_t)s->n_spheres * sizeof(rt_sphere) : 0) +
                    ((s->n_meshes <= RT_LDS_ROOTS_MAX) ? (size_t)s->n_meshes * sizeof(RootRec) : 0);
     if (c->lds_bytes > 64 * 1024) return fail(c, RT_E_INVALID, "rt_upload_scene: per-wave LDS of %zu bytes exceeds 64 KiB", c->lds_bytes);
+    /* persistent waves of the render kernel that stay resident on one CU with this scene's LDS use */
+    {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_render_kernel<false>, RT_BLOCK, c->lds_bytes) != hipSuccess || per_cu < 1) per_cu = 4;
+        const int by_regs = 4 * RT_WAVES_PER_SIMD;
+        c->waves_per_cu = per_cu < by_regs ? per_cu : by_regs;
+    }
     c->have_scene = true;
     return RT_OK;
 }
@@ -572,69 +443,6 @@ static int check_render_args(rt_ctx *c, const rt_camera *cam, const rt_params *p
     return RT_OK;
 }
 
-/* (re)allocate the wavefront state for n slots */
-static int wf_ensure(rt_ctx *c, int64_t n) {
-    if (c->wf_alloc && c->wf_cap >= n) { c->wf.n = n; goto layout; }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->wf_alloc) (void)hipFree(c->wf_alloc);
-    c->wf_alloc = nullptr;
-    {
-        const size_t bytes = (size_t)n * (WF_ND * 8 + WF_NU * 4 + 3 * 8 + 3 * 4 + 2 * 4) + 256;
-        if (hipMalloc(&c->wf_alloc, bytes) != hipSuccess) return fail(c, RT_E_NOMEM, "wavefront state allocation of %zu bytes failed", bytes);
-    }
-    c->wf_cap = n;
-    c->wf.n = n;
-layout : {
-    /* one block, carved with the CAPACITY so the layout is stable; field strides use n */
-    unsigned char *p = static_cast<unsigned char *>(c->wf_alloc);
-    const int64_t cap = c->wf_cap;
-    c->wf.d = reinterpret_cast<double *>(p); p += (size_t)cap * WF_ND * 8;
-    c->wf.hd = reinterpret_cast<double *>(p); p += (size_t)cap * 3 * 8;
-    c->wf.u = reinterpret_cast<uint32_t *>(p); p += (size_t)cap * WF_NU * 4;
-    c->wf.hi = reinterpret_cast<int32_t *>(p); p += (size_t)cap * 3 * 4;
-    c->wf.queue[0] = reinterpret_cast<int32_t *>(p); p += (size_t)cap * 4;
-    c->wf.queue[1] = reinterpret_cast<int32_t *>(p); p += (size_t)cap * 4;
-    c->wf.count = reinterpret_cast<int32_t *>(p);
-}
-    return RT_OK;
-}
-
-/* rounds between two reads of the queue length (the host sizes the grids from it) */
-static const int kRoundsPerCheck = 16;
-
-static int render_wavefront(rt_ctx *c, const RenderArgs &ra, const rt_params *p, double *accum, int64_t tiles) {
-    const int64_t n = tiles * 64;
-    int rc = wf_ensure(c, n);
-    if (rc) return rc;
-    const WfBuf b = c->wf;
-    const int kend = p->spp_offset + p->spp;
-    hipLaunchKernelGGL(rt_wf_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, b, ra, p->spp_offset);
-    HIPCHK(c, hipGetLastError());
-    c->last_launches++;
-    /* round "-1": generate the first camera rays and the first queue */
-    hipLaunchKernelGGL(rt_wf_shade, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->sc, b, ra, 0, kend, accum);
-    HIPCHK(c, hipGetLastError());
-    c->last_launches++;
-    int cur = 1;
-    int64_t known = n; /* upper bound of the queue length: it never grows */
-    for (int64_t round = 0;; round++) {
-        hipLaunchKernelGGL(rt_wf_traverse, dim3((unsigned)((known + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, b, cur, (p->flags & RT_F_NO_PRUNE) ? 0 : 1);
-        HIPCHK(c, hipGetLastError());
-        hipLaunchKernelGGL(rt_wf_shade, dim3((unsigned)((known + 255) / 256)), dim3(256), 0, c->stream, c->sc, b, ra, cur, kend, accum);
-        HIPCHK(c, hipGetLastError());
-        c->last_launches += 2;
-        cur = 1 - cur;
-        if (round % kRoundsPerCheck == kRoundsPerCheck - 1) {
-            int32_t cnt = 0;
-            HIPCHK(c, hipMemcpyAsync(&cnt, b.count + cur, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            known = cnt;
-            if (known == 0) break;
-        }
-    }
-    return RT_OK;
-}
-
 /* samples per kernel launch: long renders are cut into several launches of bounded duration */
 static const int kSppPerLaunch = 64;
 
@@ -655,11 +463,10 @@ int rt_render(rt_ctx *c, const rt_camera *cam, const rt_params *p, double *accum
     c->last_launches = 0;
     c->timed = false;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    if ((p->flags & RT_F_COUNTERS) || !(p->flags & RT_F_WAVEFRONT)) {
-        /* single persistent kernel (default, and the only counted variant) */
-        /* persistent waves: as many as stay resident (4 SIMDs x RT_WAVES_PER_SIMD per CU), each pulling 64-pixel tiles */
+    {
+        /* persistent waves: as many as stay resident, each pulling 64-pixel tiles */
         const int n_slots = (int)(tiles * RT_WAVE);
-        const unsigned pgrid = grid < (unsigned)(c->n_cus * 4 * RT_WAVES_PER_SIMD) ? grid : (unsigned)(c->n_cus * 4 * RT_WAVES_PER_SIMD);
+        const unsigned pgrid = grid < (unsigned)(c->n_cus * c->waves_per_cu) ? grid : (unsigned)(c->n_cus * c->waves_per_cu);
         for (int k = 0; k < p->spp; k += kSppPerLaunch) {
             const int nk = (p->spp - k < kSppPerLaunch) ? (p->spp - k) : kSppPerLaunch;
             HIPCHK(c, hipMemsetAsync(c->d_next_slot, 0, sizeof(int), c->stream));
@@ -670,9 +477,6 @@ int rt_render(rt_ctx *c, const rt_camera *cam, const rt_params *p, double *accum
             HIPCHK(c, hipGetLastError());
             c->last_launches++;
         }
-    } else if (p->spp > 0) {
-        rc = render_wavefront(c, ra, p, accum, tiles);
-        if (rc) return rc;
     }
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->timed = true;

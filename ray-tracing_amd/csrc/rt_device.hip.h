@@ -36,7 +36,7 @@ namespace rtd {
 #define RT_LDS_SPHERES_MAX 64     /* sphere lists up to this size are staged in LDS */
 #define RT_LDS_ROOTS_MAX 32       /* mesh root records (box + root) up to this many are staged in LDS */
 #ifndef RT_FEED_BELOW
-#define RT_FEED_BELOW 448         /* mesh roots are fed to the pool while fewer node items than this are pending (measured: the more the better) */
+#define RT_FEED_BELOW 384         /* mesh roots are fed to the pool while fewer node items than this are pending (measured: the more the better) */
 #endif
 #ifndef RT_NODE_SOFT
 #define RT_NODE_SOFT 512
@@ -47,10 +47,12 @@ namespace rtd {
 #ifndef RT_LEAF_TRIGGER
 #define RT_LEAF_TRIGGER 64        /* pending leaf items that make the next pool step a triangle step */
 #endif
-#define RT_NODE_BITS 26           /* node index bits in a node item (the ray lane takes the top 6) */
+#define RT_RAY_SLOTS 128          /* rays of one query: two per lane (slot = lane, 64 + lane) */
+#define RT_NODE_BITS 25           /* record-index / leaf-count bits in a pool item (the ray slot takes the top 7) */
+#define RT_LOW_MASK ((1u << RT_NODE_BITS) - 1u)
 #define RT_MAX_DEPTH 60
-static_assert(RT_FEED_BELOW + RT_WAVE <= RT_NODE_SOFT, "a fed mesh adds up to 64 node items on top of RT_FEED_BELOW - 1");
-static_assert(RT_LEAF_CAP >= 3 * RT_WAVE, "a node step adds up to 128 leaf items and runs only when 128 slots are free; a fed mesh adds up to 64 on top of 64");
+static_assert(RT_FEED_BELOW + 2 * RT_WAVE <= RT_NODE_SOFT, "a fed mesh adds up to 128 node items on top of RT_FEED_BELOW - 1");
+static_assert(RT_LEAF_CAP >= 3 * RT_WAVE, "a node step adds up to 128 leaf items and runs only when 128 slots are free; a fed mesh adds up to 128 on top of 64");
 #define RT_PHANTOM_BASE (1 << 30)  /* best_pos values from here on: "mesh (value - base) reports a hit without a triangle" */
 
 /* what the root phase needs of a mesh: the root box (raytracer.cpp:644) and where the tree starts */
@@ -267,17 +269,17 @@ struct HitRec {
 
 /* ---- per-wave LDS ------------------------------------------------------------------------- */
 struct WaveLDS {
-    double ray[12][RT_WAVE];              /* C, u, 1/u, -(C/u) of each lane's ray */
-    double tol[RT_WAVE];                  /* |tol|: below this the fast box test does not decide (NaN: never). The sign bit is set
+    double ray[12][RT_RAY_SLOTS];         /* C, u, 1/u, -(C/u) of each ray */
+    double tol[RT_RAY_SLOTS];             /* |tol|: below this the fast box test does not decide (NaN: never). The sign bit is set
                                              when the caller only asks whether something is hit before tmax */
-    unsigned long long best_t[RT_WAVE];   /* bits of the smallest accepted triangle t (> 0, so the bit order is the value order) */
-    double thr[RT_WAVE];                  /* distance beyond which nothing can change the ray's result */
-    int32_t best_pos[RT_WAVE];            /* lowest triangle position among those with that t */
+    unsigned long long best_t[RT_RAY_SLOTS]; /* bits of the smallest accepted triangle t (> 0, so the bit order is the value order) */
+    double thr[RT_RAY_SLOTS];             /* distance beyond which nothing can change the ray's result */
+    int32_t best_pos[RT_RAY_SLOTS];       /* lowest triangle position among those with that t */
     int32_t mark[RT_WAVE];                /* triangle step: slot -> leaf item that starts there, or -1 */
     int32_t ex[RT_WAVE];                  /* triangle step: first slot of each leaf item */
-    uint2 leaf[RT_LEAF_CAP];              /* leaf items: x = first triangle, y = count | lane << 26 */
+    uint2 leaf[RT_LEAF_CAP];              /* leaf items: x = first triangle, y = count | ray slot << 25 */
     float leaf_t[RT_LEAF_CAP];            /* entry parameter of the leaf's box, rounded down */
-    uint2 node[1];                        /* node items: x = record index | lane << 26, y = entry parameter (float bits, rounded
+    uint2 node[1];                        /* node items: x = record index | ray slot << 25, y = entry parameter (float bits, rounded
                                              down); node_cap entries, then the staged spheres */
 };
 __device__ __forceinline__ const rt_sphere *lds_spheres(const WaveLDS *w, int node_cap) {
@@ -330,108 +332,152 @@ __device__ __forceinline__ void wave_sync() {
  * distribution, so this happens about once in 1e18 hits. RT_F_NO_PRUNE visits everything. */
 #define RT_PRUNE_SLACK 1.000001
 
-/* Scene::intersect, raytracer.cpp:930-951. Called by all 64 lanes together; `active` lanes get the
- * closest hit of their ray (C, u). tmax / anyhit describe what the caller will do with the answer:
- * anyhit = it only tests "hit && t < tmax" (the shadow test, raytracer.cpp:1073), so hits at or beyond
- * tmax need not be found and the first one below it settles the ray. */
+/* One ray of a query. tmax / anyhit describe what the caller will do with the answer: anyhit = it only tests
+ * "hit && t < tmax" (the shadow test, raytracer.cpp:1073), so hits at or beyond tmax need not be found and the
+ * first one below it settles the ray. */
+struct RayQ {
+    bool active;
+    V3 C, u;
+    double tmax;
+    bool anyhit;
+};
+
+/* Spheres for one ray (Sphere::intersect, raytracer.cpp:883-918; the lowest objectId wins an exact tie, :938)
+ * and the ray's entry in the pool's tables. */
 template <bool CNT>
-__device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w, const rt_sphere *sph, const RootRec *roots, bool active, V3 C, V3 u,
-                                                   double tmax, bool anyhit, bool prune, HitRec &h, Cnt &cnt) {
-    const int lane = lane_id();
+__device__ __forceinline__ void ray_begin(const DScene &sc, WaveLDS *w, const rt_sphere *sph, int slot, const RayQ &q, bool prune, HitRec &h, Cnt &cnt) {
     h.t = 1E10;
     h.obj = INT32_MAX;
     h.prim = -1;
     h.mesh = -1;
     h.beta = h.gamma = 0;
-    uint64_t st0 = 0;
-    if (CNT) { st0 = RT_STAMP(); cnt.queries++; cnt.query_lanes += (uint64_t)__popcll(__ballot(active)); }
-    /* spheres: Sphere::intersect, raytracer.cpp:883-918; the lowest objectId wins an exact tie (:938) */
-    if (active) {
-        if (CNT) cnt.rays++;
-        for (int s = 0; s < sc.n_spheres; s++) {
-            V3 O = ld3(sph[s].O);
-            double R = sph[s].R;
-            int32_t oid = sph[s].object_id;
-            double a = 1;
-            V3 CO = sub(C, O);
-            double b = 2 * dot(u, CO);
-            double c = norm2(CO) - R * R;
-            double delta = b * b - 4 * a * c;
-            if (delta < 0) continue;
-            double sq = sqrt(delta);
-            double t2 = (-b + sq) / (2 * a);
-            if (t2 < 0) continue;
-            double t1 = (-b - sq) / (2 * a);
-            double t = (t1 > 0) ? t1 : t2;
-            if (t < h.t || (t == h.t && oid < h.obj)) { h.t = t; h.obj = oid; h.prim = s; h.mesh = -1; }
-        }
+    if (!q.active) return;
+    const V3 C = q.C, u = q.u;
+    if (CNT) cnt.rays++;
+    for (int s = 0; s < sc.n_spheres; s++) {
+        V3 O = ld3(sph[s].O);
+        double R = sph[s].R;
+        int32_t oid = sph[s].object_id;
+        double a = 1;
+        V3 CO = sub(C, O);
+        double b = 2 * dot(u, CO);
+        double c = norm2(CO) - R * R;
+        double delta = b * b - 4 * a * c;
+        if (delta < 0) continue;
+        double sq = sqrt(delta);
+        double t2 = (-b + sq) / (2 * a);
+        if (t2 < 0) continue;
+        double t1 = (-b - sq) / (2 * a);
+        double t = (t1 > 0) ? t1 : t2;
+        if (t < h.t || (t == h.t && oid < h.obj)) { h.t = t; h.obj = oid; h.prim = s; h.mesh = -1; }
     }
-    if (sc.n_meshes == 0) return h.obj != INT32_MAX;
-
+    if (sc.n_meshes == 0) return;
     /* Mesh hits are accepted only below t0 = min(1E9, sphere hit, tmax): TriangleMesh::intersect starts at
      * t = 1E9 (raytracer.cpp:647), a mesh hit beyond the closest sphere loses in Scene::intersect (:938)
      * and one beyond tmax cannot matter to the caller. A mesh hit AT t0 is still recorded (tie rules). */
     double t0 = 1E9;
     if (prune) {
         if (h.t < t0) t0 = h.t;
-        if (tmax < t0) t0 = tmax;
+        if (q.tmax < t0) t0 = q.tmax;
         if (!(t0 > 0)) t0 = 0; /* also turns -0.0 into +0.0: the bit pattern must order like the value */
     }
-    {
-        const RayK k = ray_constants(sc, C, u);
-        w->ray[0][lane] = C.x; w->ray[1][lane] = C.y; w->ray[2][lane] = C.z;
-        w->ray[3][lane] = u.x; w->ray[4][lane] = u.y; w->ray[5][lane] = u.z;
-        w->ray[6][lane] = k.iu.x; w->ray[7][lane] = k.iu.y; w->ray[8][lane] = k.iu.z;
-        w->ray[9][lane] = k.nc.x; w->ray[10][lane] = k.nc.y; w->ray[11][lane] = k.nc.z;
-        w->tol[lane] = (anyhit && prune) ? -k.tol : k.tol; /* the sign bit of a NaN is kept too */
-    }
-    w->best_t[lane] = (unsigned long long)__double_as_longlong(t0);
-    w->best_pos[lane] = INT32_MAX;
+    const RayK k = ray_constants(sc, C, u);
+    w->ray[0][slot] = C.x; w->ray[1][slot] = C.y; w->ray[2][slot] = C.z;
+    w->ray[3][slot] = u.x; w->ray[4][slot] = u.y; w->ray[5][slot] = u.z;
+    w->ray[6][slot] = k.iu.x; w->ray[7][slot] = k.iu.y; w->ray[8][slot] = k.iu.z;
+    w->ray[9][slot] = k.nc.x; w->ray[10][slot] = k.nc.y; w->ray[11][slot] = k.nc.z;
+    w->tol[slot] = (q.anyhit && prune) ? -k.tol : k.tol; /* the sign bit of a NaN is kept too */
+    w->best_t[slot] = (unsigned long long)__double_as_longlong(t0);
+    w->best_pos[slot] = INT32_MAX;
     /* While nothing closer than 1E9 is known, nothing may be skipped by distance: a triangle hit at or beyond
      * 1E9 still makes TriangleMesh::intersect return true (raytracer.cpp:689 sets has_inter before :690 compares). */
-    w->thr[lane] = (prune && t0 < 1E9) ? t0 * RT_PRUNE_SLACK : __builtin_huge_val();
+    w->thr[slot] = (prune && t0 < 1E9) ? t0 * RT_PRUNE_SLACK : __builtin_huge_val();
+}
+
+/* the mesh hit of one ray, and Scene::intersect's choice between it and the sphere hit */
+__device__ __forceinline__ void ray_end(const DScene &sc, WaveLDS *w, int slot, const RayQ &q, HitRec &h) {
+    if (!q.active) return;
+    const double tm = __longlong_as_double((long long)w->best_t[slot]);
+    const int32_t pos = w->best_pos[slot];
+    if (pos != INT32_MAX) {
+        const bool phantom = pos >= RT_PHANTOM_BASE; /* the mesh reported a hit at t = 1E9 without a triangle */
+        const int32_t mi2 = phantom ? pos - RT_PHANTOM_BASE : sc.tris[pos].mesh;
+        const double tmm = phantom ? 1E9 : tm;
+        const int32_t oid = sc.meshes[mi2].object_id;
+        if (tmm < h.t || (tmm == h.t && oid < h.obj)) {
+            h.t = tmm; h.obj = oid; h.prim = phantom ? -1 : pos; h.mesh = mi2;
+            double lt;
+            if (!phantom) (void)tri_test(sc, (uint32_t)pos, q.C, q.u, h.beta, h.gamma, lt); /* alpha, beta, gamma of the winner (:683-685) */
+        }
+    }
+}
+
+/* the mesh root box of one ray (raytracer.cpp:644) */
+template <bool CNT>
+__device__ __forceinline__ bool root_test(const DScene &sc, WaveLDS *w, const RootRec &m, int mesh, int slot, const RayQ &q, float &fn, Cnt &cnt) {
+    if (!q.active) return false;
+    RayK k;
+    k.iu = mk(w->ray[6][slot], w->ray[7][slot], w->ray[8][slot]);
+    k.nc = mk(w->ray[9][slot], w->ray[10][slot], w->ray[11][slot]);
+    k.tol = fabs(w->tol[slot]);
+    if (CNT) cnt.box_tests++;
+    bool pass, unsure;
+    double tn;
+    box_fast(Box6{(double)m.box[0], (double)m.box[1], (double)m.box[2], (double)m.box[3], (double)m.box[4], (double)m.box[5]}, k, pass, unsure, tn);
+    if (__builtin_expect(unsure, 0)) {
+        pass = box_hit_exact(sc.meshes[mesh].root_box, q.C.x, q.C.y, q.C.z, q.u.x, q.u.y, q.u.z);
+        tn = -__builtin_huge_val();
+    }
+    if (CNT && pass) cnt.mesh_calls++;
+    fn = lower_float(tn);
+    return pass && !(tn > w->thr[slot]);
+}
+
+/* Scene::intersect, raytracer.cpp:930-951, for up to two rays per lane (slots lane and 64 + lane). Called by all
+ * 64 lanes together; active rays get their closest hit. */
+template <bool CNT>
+__device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w, const rt_sphere *sph, const RootRec *roots, const RayQ &qa, const RayQ &qb,
+                                                   bool prune, HitRec &ha, HitRec &hb, Cnt &cnt) {
+    const int lane = lane_id();
+    uint64_t st0 = 0;
+    if (CNT) { st0 = RT_STAMP(); cnt.queries++; cnt.query_lanes += (uint64_t)(__popcll(__ballot(qa.active)) + __popcll(__ballot(qb.active))); }
+    ray_begin<CNT>(sc, w, sph, lane, qa, prune, ha, cnt);
+    ray_begin<CNT>(sc, w, sph, RT_WAVE + lane, qb, prune, hb, cnt);
+    if (sc.n_meshes == 0) return;
 
     int n_nodes = 0, n_leaves = 0; /* wave-uniform stack heights */
     int mi = 0;
     for (;;) {
-        /* Root boxes (raytracer.cpp:644): every lane for its own ray; roots that pass enter the pool. The
-         * next mesh is fed whenever fewer than RT_FEED_BELOW node items are pending, so the tail of one
-         * mesh's traversal shares its steps with the start of the next, and a root is already tested
-         * against the distance of the hits found so far. */
+        /* Root boxes (raytracer.cpp:644): every lane for its own rays; roots that pass enter the pool. The
+         * next mesh is fed whenever fewer than RT_FEED_BELOW node items are pending, so the traversals of
+         * the meshes share their steps, and a root is already tested against the distance of the hits
+         * found so far. */
         if (mi < sc.n_meshes && n_nodes < RT_FEED_BELOW && n_leaves <= RT_WAVE) {
-            RayK k;
-            k.iu = mk(w->ray[6][lane], w->ray[7][lane], w->ray[8][lane]);
-            k.nc = mk(w->ray[9][lane], w->ray[10][lane], w->ray[11][lane]);
-            k.tol = fabs(w->tol[lane]);
-            const double my_thr = w->thr[lane];
             do {
                 const RootRec &m = roots[mi];
+                float fa = 0.f, fb = 0.f;
+                const bool pa = root_test<CNT>(sc, w, m, mi, lane, qa, fa, cnt);
+                const bool pb = root_test<CNT>(sc, w, m, mi, RT_WAVE + lane, qb, fb, cnt);
                 mi++;
-                bool pass = false;
-                double tn = 0;
-                if (active) {
-                    if (CNT) cnt.box_tests++;
-                    bool unsure;
-                    box_fast(Box6{(double)m.box[0], (double)m.box[1], (double)m.box[2], (double)m.box[3], (double)m.box[4], (double)m.box[5]}, k, pass, unsure, tn);
-                    if (__builtin_expect(unsure, 0)) {
-                        pass = box_hit_exact(sc.meshes[mi - 1].root_box, C.x, C.y, C.z, u.x, u.y, u.z);
-                        tn = -__builtin_huge_val();
-                    }
-                    if (CNT && pass) cnt.mesh_calls++;
-                    pass = pass && !(tn > my_thr);
-                }
-                const unsigned long long bal = __ballot(pass);
-                if (bal == 0ull) continue;
-                const int r = rank_in(bal);
+                const unsigned long long ba = __ballot(pa), bb = __ballot(pb);
+                if ((ba | bb) == 0ull) continue;
+                const int ca = __popcll(ba);
                 if (m.root_count == 0) {
-                    if (pass) w->node[n_nodes + r] = make_uint2((uint32_t)m.root | ((uint32_t)lane << RT_NODE_BITS), __float_as_uint(lower_float(tn)));
-                    n_nodes = uni(n_nodes + __popcll(bal));
+                    if (pa) w->node[n_nodes + rank_in(ba)] = make_uint2((uint32_t)m.root | ((uint32_t)lane << RT_NODE_BITS), __float_as_uint(fa));
+                    if (pb) w->node[n_nodes + ca + rank_in(bb)] = make_uint2((uint32_t)m.root | ((uint32_t)(RT_WAVE + lane) << RT_NODE_BITS), __float_as_uint(fb));
+                    n_nodes = uni(n_nodes + ca + __popcll(bb));
                 } else { /* the root is itself a leaf */
-                    if (pass) {
-                        w->leaf[n_leaves + r] = make_uint2((uint32_t)m.root, (uint32_t)m.root_count | ((uint32_t)lane << 26));
-                        w->leaf_t[n_leaves + r] = lower_float(tn);
+                    if (pa) {
+                        const int qi = n_leaves + rank_in(ba);
+                        w->leaf[qi] = make_uint2((uint32_t)m.root, (uint32_t)m.root_count | ((uint32_t)lane << RT_NODE_BITS));
+                        w->leaf_t[qi] = fa;
                     }
-                    n_leaves = uni(n_leaves + __popcll(bal));
+                    if (pb) {
+                        const int qi = n_leaves + ca + rank_in(bb);
+                        w->leaf[qi] = make_uint2((uint32_t)m.root, (uint32_t)m.root_count | ((uint32_t)(RT_WAVE + lane) << RT_NODE_BITS));
+                        w->leaf_t[qi] = fb;
+                    }
+                    n_leaves = uni(n_leaves + ca + __popcll(bb));
                 }
             } while (mi < sc.n_meshes && n_nodes < RT_FEED_BELOW && n_leaves <= RT_WAVE);
             wave_sync();
@@ -453,8 +499,8 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
                 int cntl = 0;
                 if (lane < m) {
                     it = w->leaf[n_leaves - 1 - lane];
-                    cntl = (int)(it.y & 0x3FFFFFFu);
-                    if ((double)w->leaf_t[n_leaves - 1 - lane] > w->thr[it.y >> 26]) cntl = 0;
+                    cntl = (int)(it.y & RT_LOW_MASK);
+                    if ((double)w->leaf_t[n_leaves - 1 - lane] > w->thr[it.y >> RT_NODE_BITS]) cntl = 0;
                 }
                 const int incl = wave_scan_add(cntl);
                 const int excl = incl - cntl;
@@ -471,11 +517,11 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
                 int exj = 0;
                 if (have) { itj = w->leaf[n_leaves - 1 - j]; exj = w->ex[j]; }
                 const uint32_t tri = itj.x + (uint32_t)(lane - exj);
-                const int rl = (int)(itj.y >> 26);
+                const int rl = (int)(itj.y >> RT_NODE_BITS);
                 wave_sync();
                 if (lane < m && excl < RT_WAVE && incl > RT_WAVE) { /* the item cut by the last slot */
                     const uint32_t used = (uint32_t)(RT_WAVE - excl);
-                    w->leaf[n_leaves - 1 - lane] = make_uint2(it.x + used, ((uint32_t)cntl - used) | (it.y & 0xFC000000u));
+                    w->leaf[n_leaves - 1 - lane] = make_uint2(it.x + used, ((uint32_t)cntl - used) | (it.y & ~RT_LOW_MASK));
                 }
                 n_leaves = uni(n_leaves - __popcll(__ballot(lane < m && incl <= RT_WAVE)));
                 const int k = take;
@@ -545,7 +591,7 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
                 n_nodes -= k;
                 wave_sync();
                 const int rl = (int)(it.x >> RT_NODE_BITS);
-                uint32_t rec = it.x & ((1u << RT_NODE_BITS) - 1u);
+                uint32_t rec = it.x & RT_LOW_MASK;
                 if (have && rec >= sc.n_nodes_total) { /* never fetch outside the arrays */
                     have = false;
                     atomicOr(sc.overflow, 2);
@@ -596,12 +642,12 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
                 const int c2 = __popcll(b2);
                 if (pll) {
                     const int q = n_leaves + rank_in(b2);
-                    w->leaf[q] = make_uint2((uint32_t)L, (uint32_t)nL | ((uint32_t)rl << 26));
+                    w->leaf[q] = make_uint2((uint32_t)L, (uint32_t)nL | ((uint32_t)rl << RT_NODE_BITS));
                     w->leaf_t[q] = fl;
                 }
                 if (plr) {
                     const int q = n_leaves + c2 + rank_in(b3);
-                    w->leaf[q] = make_uint2((uint32_t)R, (uint32_t)nR | ((uint32_t)rl << 26));
+                    w->leaf[q] = make_uint2((uint32_t)R, (uint32_t)nR | ((uint32_t)rl << RT_NODE_BITS));
                     w->leaf_t[q] = fr;
                 }
                 n_leaves = uni(n_leaves + c2 + __popcll(b3));
@@ -610,25 +656,10 @@ __device__ __forceinline__ bool scene_closest_wave(const DScene &sc, WaveLDS *w,
             }
         }
     }
-    /* the mesh hit of this lane's ray, and Scene::intersect's choice between it and the sphere hit */
-    if (active) {
-        const double tm = __longlong_as_double((long long)w->best_t[lane]);
-        const int32_t pos = w->best_pos[lane];
-        if (pos != INT32_MAX) {
-            const bool phantom = pos >= RT_PHANTOM_BASE; /* the mesh reported a hit at t = 1E9 without a triangle */
-            const int32_t mi2 = phantom ? pos - RT_PHANTOM_BASE : sc.tris[pos].mesh;
-            const double tmm = phantom ? 1E9 : tm;
-            const int32_t oid = sc.meshes[mi2].object_id;
-            if (tmm < h.t || (tmm == h.t && oid < h.obj)) {
-                h.t = tmm; h.obj = oid; h.prim = phantom ? -1 : pos; h.mesh = mi2;
-                double lt;
-                if (!phantom) (void)tri_test(sc, (uint32_t)pos, C, u, h.beta, h.gamma, lt); /* alpha, beta, gamma of the winner (:683-685) */
-            }
-        }
-    }
+    ray_end(sc, w, lane, qa, ha);
+    ray_end(sc, w, RT_WAVE + lane, qb, hb);
     wave_sync();
     if (CNT) cnt.cyc_finish += RT_STAMP() - st0;
-    return h.obj != INT32_MAX;
 }
 
 struct Surf {
@@ -698,27 +729,30 @@ struct RenderArgs {
     int32_t j0, i0, j1, i1;
 };
 
-/* State of one pixel's sample loop between two closest-hit queries: the ray to trace next and what
- * the recursion of Scene::getColor would hold on its stack. */
+/* State of one pixel's sample loop between two queries: the rays to trace next and what the recursion of
+ * Scene::getColor would hold on its stack. A diffuse vertex leaves two rays, its shadow ray and the indirect
+ * ray (raytracer.cpp:1073, :1087); neither depends on the other's answer, so both go into the same query. */
 struct Path {
-    V3 rC, ru;      /* ray being traced */
+    V3 rC, ru;      /* path segment to trace (primary, mirror, refraction or indirect ray) */
+    V3 shC, shU;    /* shadow ray of the pending diffuse vertex */
     V3 T, Lsum;     /* throughput and radiance of the current path */
     V3 acc;         /* sum over the finished samples of this pixel (raytracer.cpp:1463, :1485) */
-    V3 nee, nextC, nextU, vAlbedo; /* pending diffuse vertex while its shadow ray is traced */
+    V3 nee, vAlbedo; /* direct light and albedo of the pending diffuse vertex */
     double sh_limit;
     uint64_t key;   /* random stream of the current sample */
     uint32_t ctr;   /* draws used so far */
     int32_t k;      /* current sample index */
     int32_t rebond;
-    bool lastDiffuse, shadow, fresh, finished;
+    bool lastDiffuse, shadow, segment, fresh, finished; /* shadow / segment: which of the two rays are to be traced */
 };
 
 __device__ __forceinline__ void path_begin(Path &q, int k0, bool live) {
     q.rC = mk(0, 0, 0); q.ru = mk(0, 0, 1);
+    q.shC = mk(0, 0, 0); q.shU = mk(0, 0, 1);
     q.T = mk(1, 1, 1); q.Lsum = mk(0, 0, 0); q.acc = mk(0, 0, 0);
-    q.nee = q.nextC = q.nextU = q.vAlbedo = mk(0, 0, 0);
+    q.nee = q.vAlbedo = mk(0, 0, 0);
     q.sh_limit = 0; q.key = 0; q.ctr = 0; q.k = k0; q.rebond = 0;
-    q.lastDiffuse = false; q.shadow = false; q.fresh = true; q.finished = !live;
+    q.lastDiffuse = false; q.shadow = false; q.segment = true; q.fresh = true; q.finished = !live;
 }
 
 /* Start the next sample of pixel (i, j) if the previous one has ended: one iteration of the k loop
@@ -758,33 +792,33 @@ __device__ __forceinline__ void path_fresh(const RenderArgs &ra, Path &q, int i,
     q.rebond = 0;
     q.lastDiffuse = false;
     q.shadow = false;
+    q.segment = true;
     q.fresh = false;
 }
 
-/* One step of Scene::getColor (raytracer.cpp:953-1093) given the closest hit of the ray that was
- * traced: either the pending shadow ray of a diffuse vertex or a path segment. Leaves the next ray
- * in (rC, ru) or ends the sample (fresh = true). */
+/* One step of Scene::getColor (raytracer.cpp:953-1093) given the answers of the rays that were traced: first the
+ * shadow ray of the pending diffuse vertex (hs), then the path segment (h), in the order the recursion adds their
+ * terms. Leaves the next ray(s) in the state or ends the sample (fresh = true). */
 template <bool CNT>
 __device__ __forceinline__ void path_advance(const DScene &sc, const rt_sphere *sph, const RenderArgs &ra, Path &q, bool inter,
-                                             const HitRec &h, Cnt &cnt) {
+                                             const HitRec &h, bool inter_s, const HitRec &hs, Cnt &cnt) {
     const rt_params &p = ra.p;
     const uint32_t fl = p.flags;
     const double epsilon = p.epsilon;
     bool done = false;
     if (q.shadow) {
         /* raytracer.cpp:1073-1083 (or :1048-1055 for the point light): occluded iff hit before the light */
-        if (!(inter && h.t < q.sh_limit)) q.Lsum = add(q.Lsum, cmul(q.T, q.nee));
+        if (!(inter_s && hs.t < q.sh_limit)) q.Lsum = add(q.Lsum, cmul(q.T, q.nee));
         q.shadow = false;
-        if (fl & RT_F_NO_INDIRECT) {
-            done = true;
-        } else {
-            /* color += albedo * getColor(wiRay, rebond + 1, true), raytracer.cpp:1086-1088 */
+        if (q.segment) {
+            /* color += albedo * getColor(wiRay, rebond + 1, true), raytracer.cpp:1086-1088: (h) is that ray's hit */
             q.T = cmul(q.T, q.vAlbedo);
-            q.rC = q.nextC;
-            q.ru = q.nextU;
             q.rebond++;
             q.lastDiffuse = true;
         }
+    }
+    if (!q.segment) { /* RT_F_NO_INDIRECT: the vertex had no indirect ray */
+        done = true;
     } else if (q.rebond > p.max_rebond || !inter) {
         /* the query comes before the depth test (:960-963) */
         done = true;
@@ -838,7 +872,7 @@ __device__ __forceinline__ void path_advance(const DScene &sc, const rt_sphere *
             }
             q.rebond++;
             q.lastDiffuse = false;
-        } else { /* diffuse: direct light now, indirect ray after the shadow query */
+        } else { /* diffuse: the shadow ray and the indirect ray, traced together */
             if (CNT) cnt.diffuse++;
             const V3 Lpos = ld3(sc.L);
             V3 shC = add(P, smul(0.00001, N)), shU;
@@ -869,12 +903,14 @@ __device__ __forceinline__ void path_advance(const DScene &sc, const rt_sphere *
             if (!(fl & RT_F_NO_INDIRECT)) { /* :1086-1087; its two draws follow the light's two */
                 double u1 = rng_uniform(q.key, q.ctr), u2 = rng_uniform(q.key, q.ctr + 1);
                 q.ctr += 2;
-                q.nextU = random_cos(u1, u2, N);
-                q.nextC = add(P, smul(epsilon, N));
+                q.ru = random_cos(u1, u2, N);
+                q.rC = add(P, smul(epsilon, N));
                 q.vAlbedo = s.albedo;
+            } else {
+                q.segment = false;
             }
-            q.rC = shC;
-            q.ru = shU;
+            q.shC = shC;
+            q.shU = shU;
             q.shadow = true;
         }
     }
@@ -900,11 +936,12 @@ __device__ __forceinline__ V3 trace_pixel(const DScene &sc, WaveLDS *w, const rt
         path_fresh<CNT>(ra, q, i, j, kend, cnt);
         if (__ballot(!q.finished) == 0ull) break;
         if (CNT) cnt.cyc_fresh += RT_STAMP() - sp0;
-        HitRec h;
-        bool inter = scene_closest_wave<CNT>(sc, w, sph, roots, !q.finished, q.rC, q.ru, q.shadow ? q.sh_limit : 1E10, q.shadow,
-                                             !(ra.p.flags & RT_F_NO_PRUNE), h, cnt);
+        HitRec h, hs;
+        const RayQ qa = RayQ{!q.finished && q.segment, q.rC, q.ru, 1E10, false};
+        const RayQ qb = RayQ{!q.finished && q.shadow, q.shC, q.shU, q.sh_limit, true};
+        scene_closest_wave<CNT>(sc, w, sph, roots, qa, qb, !(ra.p.flags & RT_F_NO_PRUNE), h, hs, cnt);
         if (CNT) sp0 = RT_STAMP();
-        if (!q.finished) path_advance<CNT>(sc, sph, ra, q, inter, h, cnt);
+        if (!q.finished) path_advance<CNT>(sc, sph, ra, q, h.obj != INT32_MAX, h, hs.obj != INT32_MAX, hs, cnt);
         if (CNT) cnt.cyc_shade += RT_STAMP() - sp0;
     }
     return q.acc;
@@ -974,11 +1011,12 @@ __device__ __forceinline__ void render_persistent(const DScene &sc, WaveLDS *w, 
             continue; /* nothing to trace this round: only bookkeeping (pixels ended or were just assigned) */
         }
         if (CNT) cnt.cyc_fresh += RT_STAMP() - sp0;
-        HitRec h;
-        bool inter = scene_closest_wave<CNT>(sc, w, sph, roots, !q.finished, q.rC, q.ru, q.shadow ? q.sh_limit : 1E10, q.shadow,
-                                             !(ra.p.flags & RT_F_NO_PRUNE), h, cnt);
+        HitRec h, hs;
+        const RayQ qa = RayQ{!q.finished && q.segment, q.rC, q.ru, 1E10, false};
+        const RayQ qb = RayQ{!q.finished && q.shadow, q.shC, q.shU, q.sh_limit, true};
+        scene_closest_wave<CNT>(sc, w, sph, roots, qa, qb, !(ra.p.flags & RT_F_NO_PRUNE), h, hs, cnt);
         if (CNT) sp0 = RT_STAMP();
-        if (!q.finished) path_advance<CNT>(sc, sph, ra, q, inter, h, cnt);
+        if (!q.finished) path_advance<CNT>(sc, sph, ra, q, h.obj != INT32_MAX, h, hs.obj != INT32_MAX, hs, cnt);
         if (CNT) cnt.cyc_shade += RT_STAMP() - sp0;
     }
 }

@@ -130,12 +130,12 @@ class TestFullSize:
         b = gpu.accum_download(W, W)
         assert np.allclose(a, b, rtol=1e-13, atol=1e-9)
 
-    def test_pruned_equals_unpruned_and_wavefront(self, gpu, rta, full):
+    def test_pruned_equals_unpruned_and_counted(self, gpu, rta, full):
         s, cam, flags = full
         W = 1024
         rect = (448, 448, 576, 576)
         out = []
-        for fl in (0, rta.RT_F_NO_PRUNE, rta.RT_F_WAVEFRONT):
+        for fl in (0, rta.RT_F_NO_PRUNE, rta.RT_F_COUNTERS):
             gpu.accum_clear(W, W)
             gpu.render(cam, rta.make_params(W, W, 3, flags=flags | fl, rect=rect))
             out.append(gpu.accum_download(W, W))

@@ -261,9 +261,6 @@ def test_pruning_changes_work_not_results(gpu, rta, scenes, ob):
         gpu.accum_clear(W, W)
         gpu.render(cam, rta.make_params(W, W, 3, flags=fl))
         out[name] = gpu.accum_download(W, W)
-        gpu.accum_clear(W, W)
-        gpu.render(cam, rta.make_params(W, W, 3, flags=fl | rta.RT_F_WAVEFRONT))
-        assert np.array_equal(gpu.accum_download(W, W), out[name], equal_nan=True)  # two-kernel form == single kernel
         gpu.reset_counters()
         gpu.accum_clear(W, W)
         gpu.render(cam, rta.make_params(W, W, 3, flags=fl | rta.RT_F_COUNTERS))

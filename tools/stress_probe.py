@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""cfg5-style stress scene: upload + render timing and a parity spot check against the oracle on a few samples."""
+import importlib, os, sys, json, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+rta = importlib.import_module("ray-tracing_amd"); scenes = importlib.import_module("ray-tracing_amd.scenes")
+from oracle import bindings as ob
+n_tris = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+n_sph = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+W = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+t0 = time.time(); s, cam, fl = scenes.stress(W=W, n_tris=n_tris, n_spheres=n_sph); t1 = time.time()
+r = rta.Renderer(0); r.upload(s); info = s.flat_info(); t2 = time.time()
+r.accum_clear(W, W)
+r.render(cam, rta.make_params(W, W, 1, flags=fl)); r.sync()
+r.render(cam, rta.make_params(W, W, 4, spp_offset=1, flags=fl)); r.sync()
+ms = r.last_render_ms()[0]
+out = dict(n_tris=info["n_tris"], n_spheres=info["n_spheres"], MB=round(info["bytes"] / 1e6, 1), build_s=round(t1 - t0, 1), upload_s=round(t2 - t1, 1),
+           Mpaths_s=round(W * W * 4 / ms / 1e3, 2))
+if n_tris <= 2_000_000:
+    orc = ob.OracleScene(scenes.export_objects(s), s.I, s.L)
+    ijk = np.array([(i, j, 0) for i in range(100, W, W // 12) for j in range(50, W, W // 12)], np.int32)
+    p = rta.make_params(W, W, 1, flags=fl)
+    g, o = r.sample_radiance(cam, p, ijk), orc.sample_radiance(cam, p, ijk)
+    rel = np.abs(g - o) / np.maximum(np.abs(o), 1e-3)
+    out["parity_samples"] = len(ijk); out["parity_bad"] = int((rel.max(1) > 1e-9).sum())
+    rays, _ = ob.primary_rays(cam, W, W)
+    sel = rays[:: max(1, len(rays) // 20000)]
+    hg, ho = r.intersect_rays(sel), orc.intersect_rays(sel)
+    out["hits_equal"] = bool(np.array_equal(hg["obj"], ho["obj"]) and np.array_equal(hg["tri"], ho["tri"]) and np.array_equal(hg["t"], ho["t"]))
+print(json.dumps(out))
