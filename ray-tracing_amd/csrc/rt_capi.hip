@@ -264,6 +264,34 @@ const char *rt_last_error(const rt_ctx *c) { return c ? c->err.c_str() : g_creat
 
 void *rt_stream(rt_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
+/* a pending extension record: the leaf range it splits and where its index has to be written */
+struct ExtJob {
+    int64_t parent; /* record index, or -1 - mesh for a mesh whose root is a leaf */
+    int side;
+    int32_t first, count;
+    int depth;
+};
+
+/* float box of triangles [first, first + n), rounded outwards */
+static void tri_range_box(const rt_tri *tris, int32_t first, int32_t n, float *box) {
+    double lo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, hi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+    for (int32_t k = first; k < first + n; k++) {
+        const rt_tri &t = tris[k];
+        for (int a = 0; a < 3; a++) {
+            const double v[3] = {t.A[a], t.A[a] + t.e1[a], t.A[a] + t.e2[a]};
+            for (int q = 0; q < 3; q++) {
+                if (v[q] < lo[a]) lo[a] = v[q];
+                if (v[q] > hi[a]) hi[a] = v[q];
+                if (!(v[q] == v[q])) { lo[a] = -HUGE_VAL; hi[a] = HUGE_VAL; } /* a NaN vertex: never filter */
+            }
+        }
+    }
+    for (int a = 0; a < 3; a++) {
+        box[a] = nextafterf((float)lo[a], -HUGE_VALF);
+        box[3 + a] = nextafterf((float)hi[a], HUGE_VALF);
+    }
+}
+
 int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
     if (!c) return RT_E_INVALID;
     if (!s) return fail(c, RT_E_INVALID, "rt_upload_scene: scene is NULL");
@@ -345,6 +373,8 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
     free_scene(c);
     DScene d{};
     int rc;
+    int ext_depth = 0;
+    std::vector<int32_t> ext_root((size_t)s->n_meshes, -1); /* extension record that replaces a mesh's root leaf */
     if ((rc = upload_array(c, s->spheres, (size_t)s->n_spheres, &d.spheres))) return rc;
     if ((rc = upload_array(c, s->meshes, (size_t)s->n_meshes, &d.meshes))) return rc;
     {
@@ -366,7 +396,43 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
             rec32[(size_t)k].L = nd.L; rec32[(size_t)k].R = nd.R;
             rec32[(size_t)k].nL = nd.nL; rec32[(size_t)k].nR = nd.nR;
         }
+        /* Extension records: the reference's builder leaves ranges of up to hundreds of triangles unsplit (:283). Such a
+         * leaf is given a tree of its own over contiguous sub-ranges of its triangles (their order, which carries the
+         * tie rule, is untouched). These boxes are a filter only - a ray is kept out of a sub-range just when it
+         * certainly misses its box - so they change which triangles are tested, never the result. */
+        ext_depth = 0;
+        {
+            std::vector<ExtJob> jobs;
+            for (int64_t k = 0; k < s->n_nodes; k++) {
+                if (rec32[(size_t)k].nL > RT_EXT_LEAF) jobs.push_back(ExtJob{k, 0, rec32[(size_t)k].L, rec32[(size_t)k].nL, 1});
+                if (rec32[(size_t)k].nR > RT_EXT_LEAF) jobs.push_back(ExtJob{k, 1, rec32[(size_t)k].R, rec32[(size_t)k].nR, 1});
+            }
+            for (int mi = 0; mi < s->n_meshes; mi++)
+                if (s->meshes[mi].root_count > RT_EXT_LEAF) jobs.push_back(ExtJob{-1 - (int64_t)mi, 0, s->meshes[mi].root, s->meshes[mi].root_count, 1});
+            for (size_t q = 0; q < jobs.size(); q++) { /* breadth-first: children always get a larger index than their parent */
+                const ExtJob jb = jobs[q];
+                const int64_t id = (int64_t)rec32.size();
+                if (id >= (1LL << RT_NODE_BITS)) return fail(c, RT_E_INVALID, "rt_upload_scene: more than 2^25 BVH records with the extension records");
+                NodeRec32 r;
+                const int32_t nl = jb.count / 2, nr = jb.count - nl;
+                tri_range_box(s->tris, jb.first, nl, r.boxL);
+                tri_range_box(s->tris, jb.first + nl, nr, r.boxR);
+                r.L = jb.first; r.nL = nl;
+                r.R = jb.first + nl; r.nR = nr;
+                rec32.push_back(r);
+                if (jb.parent >= 0) { /* the parent's leaf entry becomes an inner child */
+                    NodeRec32 &pr = rec32[(size_t)jb.parent];
+                    if (jb.side == 0) { pr.L = (int32_t)id; pr.nL = 0; } else { pr.R = (int32_t)id; pr.nR = 0; }
+                } else {
+                    ext_root[(size_t)(-1 - jb.parent)] = (int32_t)id;
+                }
+                if (jb.depth > ext_depth) ext_depth = jb.depth;
+                if (nl > RT_EXT_LEAF) jobs.push_back(ExtJob{id, 0, jb.first, nl, jb.depth + 1});
+                if (nr > RT_EXT_LEAF) jobs.push_back(ExtJob{id, 1, jb.first + nl, nr, jb.depth + 1});
+            }
+        }
         if ((rc = upload_array(c, rec32.data(), rec32.size(), &d.rec32))) return rc;
+        d.n_nodes_total = (uint32_t)rec32.size();
         if ((rc = upload_array(c, halves.data(), halves.size(), &d.halves))) return rc;
         if ((rc = upload_array(c, s->tris, (size_t)s->n_tris, &d.tris))) return rc;
         HIPCHK(c, hipStreamSynchronize(c->stream)); /* the staging vectors go out of scope */
@@ -381,6 +447,7 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
             for (int k = 0; k < 6; k++) rr[mi].box[k] = (float)s->meshes[mi].root_box[k];
             rr[mi].root = s->meshes[mi].root;
             rr[mi].root_count = s->meshes[mi].root_count;
+            if (ext_root[(size_t)mi] >= 0) { rr[mi].root = ext_root[(size_t)mi]; rr[mi].root_count = 0; }
         }
         if ((rc = upload_array(c, rr.data(), rr.size(), &d.roots))) return rc;
         HIPCHK(c, hipStreamSynchronize(c->stream)); /* rr goes out of scope */
@@ -399,11 +466,11 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
         d.lightR = light->R;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream)); /* host arrays may be released after return */
-    d.node_cap = RT_NODE_SOFT + max_depth + 2;
+    d.node_cap = RT_NODE_SOFT + max_depth + ext_depth + 2;
     d.overflow = c->d_overflow;
     for (int k = 0; k < 3; k++) d.bmax[k] = bmax[k];
     d.n_tris_total = (uint32_t)s->n_tris;
-    d.n_nodes_total = (uint32_t)s->n_nodes;
+    d.n_ref_nodes = (uint32_t)s->n_nodes;
     c->sc = d;
     c->lds_bytes = sizeof(WaveLDS) + (size_t)d.node_cap * 8 + 16 + ((s->n_spheres <= RT_LDS_SPHERES_MAX) ? (size_t)s->n_spheres * sizeof(rt_sphere) : 0) +
                    ((s->n_meshes <= RT_LDS_ROOTS_MAX) ? (size_t)s->n_meshes * sizeof(RootRec) : 0);

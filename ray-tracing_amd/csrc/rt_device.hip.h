@@ -51,6 +51,9 @@ namespace rtd {
 #define RT_NODE_BITS 25           /* record-index / leaf-count bits in a pool item (the ray slot takes the top 7) */
 #define RT_LOW_MASK ((1u << RT_NODE_BITS) - 1u)
 #define RT_MAX_DEPTH 60
+#ifndef RT_EXT_LEAF
+#define RT_EXT_LEAF 8             /* reference leaves with more triangles than this get extension records down to this size */
+#endif
 static_assert(RT_FEED_BELOW + 2 * RT_WAVE <= RT_NODE_SOFT, "a fed mesh adds up to 128 node items on top of RT_FEED_BELOW - 1");
 static_assert(RT_LEAF_CAP >= 3 * RT_WAVE, "a node step adds up to 128 leaf items and runs only when 128 slots are free; a fed mesh adds up to 128 on top of 64");
 #define RT_PHANTOM_BASE (1 << 30)  /* best_pos values from here on: "mesh (value - base) reports a hit without a triangle" */
@@ -95,6 +98,7 @@ struct DScene {
     int32_t pad;
     double bmax[3];   /* largest |coordinate| of any box of the scene, per axis (infinity if one is not finite) */
     uint32_t n_tris_total, n_nodes_total; /* array lengths: every index taken from the pool is checked against them */
+    uint32_t n_ref_nodes;                 /* records below this index are the reference's; the rest are extension records */
     int *overflow;    /* bit 0: a push would have passed a stack's capacity; bit 1: an index outside the arrays */
     double I;
     double L[3];
@@ -605,7 +609,8 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
                 rk.nc = mk(w->ray[9][rl], w->ray[10][rl], w->ray[11][rl]);
                 rk.tol = fabs(w->tol[rl]);
                 have = have && !((double)__uint_as_float(it.y) > thr); /* fallen behind the threshold since it was pushed */
-                if (CNT && have) { cnt.nodes++; cnt.box_tests += 2; }
+                const bool ext = rec >= sc.n_ref_nodes; /* a filter of this implementation, not a record of the reference */
+                if (CNT && have && !ext) { cnt.nodes++; cnt.box_tests += 2; }
                 int32_t L = __float_as_int(q3.x), R = __float_as_int(q3.y);
                 const int32_t nL = __float_as_int(q3.z), nR = __float_as_int(q3.w);
                 const Box6 bl = Box6{(double)q0.x, (double)q0.y, (double)q0.z, (double)q0.w, (double)q1.x, (double)q1.y};
@@ -614,7 +619,11 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
                 double tl, tr;
                 box_fast(bl, rk, hl, ul, tl);
                 box_fast(br, rk, hr, ur, tr);
-                if (__builtin_expect(have && (ul || ur), 0)) { /* rare: the double boxes and true divisions, as the reference does them */
+                if (ext) { /* kept out only by a certain miss; with RT_F_NO_PRUNE every triangle the reference tests is tested */
+                    hl = hl || ul || !prune;
+                    hr = hr || ur || !prune;
+                    if (!prune) tl = tr = -__builtin_huge_val();
+                } else if (__builtin_expect(have && (ul || ur), 0)) { /* rare: the double boxes and true divisions, as the reference does them */
                     const double cx = w->ray[0][rl], cy = w->ray[1][rl], cz = w->ray[2][rl];
                     const double ux = w->ray[3][rl], uy = w->ray[4][rl], uz = w->ray[5][rl];
                     if (ul) { hl = box_hit_exact(sc.halves[(size_t)rec * 2].box, cx, cy, cz, ux, uy, uz); tl = -__builtin_huge_val(); }
