@@ -292,6 +292,41 @@ static void tri_range_box(const rt_tri *tris, int32_t first, int32_t n, float *b
     }
 }
 
+#define RT_EXT_SAH_DEPTH 24 /* below this depth of extension records a range is simply halved (bounds the depth) */
+
+static inline void grow(double *lo, double *hi, const rt_tri &t) {
+    for (int a = 0; a < 3; a++) {
+        const double v[3] = {t.A[a], t.A[a] + t.e1[a], t.A[a] + t.e2[a]};
+        for (int q = 0; q < 3; q++) {
+            if (v[q] < lo[a]) lo[a] = v[q];
+            if (v[q] > hi[a]) hi[a] = v[q];
+        }
+    }
+}
+static inline double half_area(const double *lo, const double *hi) {
+    const double x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+    return x * y + y * z + z * x;
+}
+/* Where to cut triangles [first, first + n) into two contiguous parts: the cut with the least surface-area cost
+ * (area of each part's box times its triangle count). The order of the triangles is fixed, so only n - 1 cuts exist. */
+static int32_t ext_split(const rt_tri *tris, int32_t first, int32_t n, std::vector<double> &right_area) {
+    right_area.resize((size_t)n + 1);
+    double lo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, hi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+    for (int32_t k = n - 1; k >= 1; k--) {
+        grow(lo, hi, tris[first + k]);
+        right_area[(size_t)k] = half_area(lo, hi);
+    }
+    for (int a = 0; a < 3; a++) { lo[a] = HUGE_VAL; hi[a] = -HUGE_VAL; }
+    int32_t best = n / 2;
+    double best_cost = HUGE_VAL;
+    for (int32_t k = 1; k < n; k++) { /* k triangles on the left */
+        grow(lo, hi, tris[first + k - 1]);
+        const double cost = half_area(lo, hi) * k + right_area[(size_t)k] * (n - k);
+        if (cost < best_cost) { best_cost = cost; best = k; }
+    }
+    return best;
+}
+
 int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
     if (!c) return RT_E_INVALID;
     if (!s) return fail(c, RT_E_INVALID, "rt_upload_scene: scene is NULL");
@@ -403,6 +438,7 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
         ext_depth = 0;
         {
             std::vector<ExtJob> jobs;
+            std::vector<double> sweep;
             for (int64_t k = 0; k < s->n_nodes; k++) {
                 if (rec32[(size_t)k].nL > RT_EXT_LEAF) jobs.push_back(ExtJob{k, 0, rec32[(size_t)k].L, rec32[(size_t)k].nL, 1});
                 if (rec32[(size_t)k].nR > RT_EXT_LEAF) jobs.push_back(ExtJob{k, 1, rec32[(size_t)k].R, rec32[(size_t)k].nR, 1});
@@ -414,7 +450,8 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
                 const int64_t id = (int64_t)rec32.size();
                 if (id >= (1LL << RT_NODE_BITS)) return fail(c, RT_E_INVALID, "rt_upload_scene: more than 2^25 BVH records with the extension records");
                 NodeRec32 r;
-                const int32_t nl = jb.count / 2, nr = jb.count - nl;
+                const int32_t nl = (jb.depth <= RT_EXT_SAH_DEPTH) ? ext_split(s->tris, jb.first, jb.count, sweep) : jb.count / 2;
+                const int32_t nr = jb.count - nl;
                 tri_range_box(s->tris, jb.first, nl, r.boxL);
                 tri_range_box(s->tris, jb.first + nl, nr, r.boxR);
                 r.L = jb.first; r.nL = nl;

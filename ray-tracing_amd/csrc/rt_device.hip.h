@@ -52,7 +52,7 @@ namespace rtd {
 #define RT_LOW_MASK ((1u << RT_NODE_BITS) - 1u)
 #define RT_MAX_DEPTH 60
 #ifndef RT_EXT_LEAF
-#define RT_EXT_LEAF 8             /* reference leaves with more triangles than this get extension records down to this size */
+#define RT_EXT_LEAF 4             /* reference leaves with more triangles than this get extension records down to this size */
 #endif
 static_assert(RT_FEED_BELOW + 2 * RT_WAVE <= RT_NODE_SOFT, "a fed mesh adds up to 128 node items on top of RT_FEED_BELOW - 1");
 static_assert(RT_LEAF_CAP >= 3 * RT_WAVE, "a node step adds up to 128 leaf items and runs only when 128 slots are free; a fed mesh adds up to 128 on top of 64");
