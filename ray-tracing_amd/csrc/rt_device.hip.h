@@ -416,14 +416,10 @@ __device__ __forceinline__ void ray_end(const DScene &sc, WaveLDS *w, int slot, 
     }
 }
 
-/* the mesh root box of one ray (raytracer.cpp:644) */
+/* the mesh root box of one ray (raytracer.cpp:644); k and thr are the ray's constants as read at the start of the feed */
 template <bool CNT>
-__device__ __forceinline__ bool root_test(const DScene &sc, WaveLDS *w, const RootRec &m, int mesh, int slot, const RayQ &q, float &fn, Cnt &cnt) {
+__device__ __forceinline__ bool root_test(const DScene &sc, const RootRec &m, int mesh, const RayQ &q, const RayK &k, double thr, float &fn, Cnt &cnt) {
     if (!q.active) return false;
-    RayK k;
-    k.iu = mk(w->ray[6][slot], w->ray[7][slot], w->ray[8][slot]);
-    k.nc = mk(w->ray[9][slot], w->ray[10][slot], w->ray[11][slot]);
-    k.tol = fabs(w->tol[slot]);
     if (CNT) cnt.box_tests++;
     bool pass, unsure;
     double tn;
@@ -434,7 +430,16 @@ __device__ __forceinline__ bool root_test(const DScene &sc, WaveLDS *w, const Ro
     }
     if (CNT && pass) cnt.mesh_calls++;
     fn = lower_float(tn);
-    return pass && !(tn > w->thr[slot]);
+    return pass && !(tn > thr);
+}
+
+/* a ray's constants of the fast box test, back from the pool's tables */
+__device__ __forceinline__ RayK ray_k_from_lds(const WaveLDS *w, int slot) {
+    RayK k;
+    k.iu = mk(w->ray[6][slot], w->ray[7][slot], w->ray[8][slot]);
+    k.nc = mk(w->ray[9][slot], w->ray[10][slot], w->ray[11][slot]);
+    k.tol = fabs(w->tol[slot]);
+    return k;
 }
 
 /* Scene::intersect, raytracer.cpp:930-951, for up to two rays per lane (slots lane and 64 + lane). Called by all
@@ -457,11 +462,13 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
          * the meshes share their steps, and a root is already tested against the distance of the hits
          * found so far. */
         if (mi < sc.n_meshes && n_nodes < RT_FEED_BELOW && n_leaves <= RT_WAVE) {
+            const RayK ka = ray_k_from_lds(w, lane), kb = ray_k_from_lds(w, RT_WAVE + lane);
+            const double thr_a = w->thr[lane], thr_b = w->thr[RT_WAVE + lane]; /* as of now: thresholds only fall */
             do {
                 const RootRec &m = roots[mi];
                 float fa = 0.f, fb = 0.f;
-                const bool pa = root_test<CNT>(sc, w, m, mi, lane, qa, fa, cnt);
-                const bool pb = root_test<CNT>(sc, w, m, mi, RT_WAVE + lane, qb, fb, cnt);
+                const bool pa = root_test<CNT>(sc, m, mi, qa, ka, thr_a, fa, cnt);
+                const bool pb = root_test<CNT>(sc, m, mi, qb, kb, thr_b, fb, cnt);
                 mi++;
                 const unsigned long long ba = __ballot(pa), bb = __ballot(pb);
                 if ((ba | bb) == 0ull) continue;
