@@ -13,6 +13,7 @@
 
 #include "rt_amd.h"
 #include "rt_device.hip.h"
+#include "rt_own_bvh.hpp"
 
 using namespace rtd;
 
@@ -408,7 +409,7 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
     free_scene(c);
     DScene d{};
     int rc;
-    int ext_depth = 0;
+    int ext_depth = 0, own_depth = 0;
     std::vector<int32_t> ext_root((size_t)s->n_meshes, -1); /* extension record that replaces a mesh's root leaf */
     if ((rc = upload_array(c, s->spheres, (size_t)s->n_spheres, &d.spheres))) return rc;
     if ((rc = upload_array(c, s->meshes, (size_t)s->n_meshes, &d.meshes))) return rc;
@@ -468,6 +469,41 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
                 if (nr > RT_EXT_LEAF) jobs.push_back(ExtJob{id, 1, jb.first + nl, nr, jb.depth + 1});
             }
         }
+        /* the filter tree over all triangles, and what confirms its winners: the reference leaf of every triangle */
+        if (s->n_tris > 0) {
+            rtown::Built own = rtown::build(s->tris, s->n_tris);
+            if (own.ok && (int64_t)own.nodes.size() < (1LL << RT_NODE_BITS)) {
+                std::vector<rt_tri> otris((size_t)s->n_tris);
+                for (int64_t k = 0; k < s->n_tris; k++) {
+                    otris[(size_t)k] = s->tris[own.order[(size_t)k]];
+                    otris[(size_t)k].orig_id = own.order[(size_t)k]; /* position in the reference's order */
+                }
+                std::vector<int32_t> tri_leaf((size_t)s->n_tris, -1);
+                std::vector<float> leaf_box;
+                auto add_leaf = [&](const double *box, int32_t first, int32_t count) {
+                    const int32_t id = (int32_t)(leaf_box.size() / 6);
+                    for (int a = 0; a < 6; a++) leaf_box.push_back((float)box[a]);
+                    for (int32_t k = first; k < first + count; k++) tri_leaf[(size_t)k] = id;
+                };
+                for (int64_t k = 0; k < s->n_nodes; k++) {
+                    if (s->nodes[k].nL > 0) add_leaf(s->nodes[k].boxL, s->nodes[k].L, s->nodes[k].nL);
+                    if (s->nodes[k].nR > 0) add_leaf(s->nodes[k].boxR, s->nodes[k].R, s->nodes[k].nR);
+                }
+                for (int mi = 0; mi < s->n_meshes; mi++)
+                    if (s->meshes[mi].root_count > 0) add_leaf(s->meshes[mi].root_box, s->meshes[mi].root, s->meshes[mi].root_count);
+                bool covered = true;
+                for (int64_t k = 0; k < s->n_tris; k++) covered = covered && tri_leaf[(size_t)k] >= 0;
+                if (covered) { /* a triangle outside every leaf is never reached by the reference: such a scene keeps to its trees */
+                    if ((rc = upload_array(c, own.nodes.data(), own.nodes.size(), &d.own_rec32))) return rc;
+                    if ((rc = upload_array(c, otris.data(), otris.size(), &d.own_tris))) return rc;
+                    if ((rc = upload_array(c, tri_leaf.data(), tri_leaf.size(), &d.tri_leaf))) return rc;
+                    if ((rc = upload_array(c, leaf_box.data(), leaf_box.size(), &d.leaf_box32))) return rc;
+                    d.n_own_nodes = (uint32_t)own.nodes.size();
+                    if (own.depth > ext_depth + max_depth) own_depth = own.depth;
+                    HIPCHK(c, hipStreamSynchronize(c->stream));
+                }
+            }
+        }
         if ((rc = upload_array(c, rec32.data(), rec32.size(), &d.rec32))) return rc;
         d.n_nodes_total = (uint32_t)rec32.size();
         if ((rc = upload_array(c, halves.data(), halves.size(), &d.halves))) return rc;
@@ -503,7 +539,7 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
         d.lightR = light->R;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream)); /* host arrays may be released after return */
-    d.node_cap = RT_NODE_SOFT + max_depth + ext_depth + 2;
+    d.node_cap = RT_NODE_SOFT + (own_depth > max_depth + ext_depth ? own_depth : max_depth + ext_depth) + 2;
     d.overflow = c->d_overflow;
     for (int k = 0; k < 3; k++) d.bmax[k] = bmax[k];
     d.n_tris_total = (uint32_t)s->n_tris;

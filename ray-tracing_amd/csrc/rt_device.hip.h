@@ -88,6 +88,13 @@ struct DScene {
     const rt_mesh *meshes;
     const NodeHalf *halves;   /* 2 per BVH record */
     const NodeRec32 *rec32;   /* 1 per BVH record, boxes in float */
+    /* the filter tree over all triangles of the scene (rt_own_bvh.hpp); null when it could not be built */
+    const NodeRec32 *own_rec32;
+    const rt_tri *own_tris;   /* triangles in the filter tree's order; orig_id holds the position in `tris` */
+    const int32_t *tri_leaf;  /* by triangle position: index of the reference leaf that holds it */
+    const float *leaf_box32;  /* 6 floats per reference leaf: its box rounded to float (to nearest) */
+    uint32_t n_own_nodes;
+    int32_t pad_own;
     const rt_tri *tris;       /* by triangle position (80 bytes each: a leaf's triangles are contiguous) */
     const rt_tri_attr *attrs;
     const rt_texture *tex;
@@ -239,13 +246,15 @@ __device__ __forceinline__ void pin3(V3 &a) { pin(a.x); pin(a.y); pin(a.z); }
 
 struct Tri3 {
     V3 A, e1, e2;
+    int32_t id; /* rt_tri::orig_id */
 };
-__device__ __forceinline__ Tri3 tri_load(const DScene &sc, uint32_t pos) {
-    const rt_tri *tr = sc.tris + pos;
+__device__ __forceinline__ Tri3 tri_load(const rt_tri *base, uint32_t pos) {
+    const rt_tri *tr = base + pos;
     Tri3 t;
     t.A = ld3(tr->A);
     t.e1 = ld3(tr->e1);
     t.e2 = ld3(tr->e2);
+    t.id = tr->orig_id;
     return t;
 }
 __device__ __forceinline__ bool tri_eval(const Tri3 &t, V3 C, V3 u, double &beta, double &gamma, double &localt) {
@@ -258,7 +267,7 @@ __device__ __forceinline__ bool tri_eval(const Tri3 &t, V3 C, V3 u, double &beta
     return beta >= 0 && gamma >= 0 && beta <= 1 && gamma <= 1 && alpha >= 0 && localt > 0;
 }
 __device__ __forceinline__ bool tri_test(const DScene &sc, uint32_t pos, V3 C, V3 u, double &beta, double &gamma, double &localt) {
-    const Tri3 t = tri_load(sc, pos);
+    const Tri3 t = tri_load(sc.tris, pos);
     return tri_eval(t, C, u, beta, gamma, localt);
 }
 
@@ -398,13 +407,30 @@ __device__ __forceinline__ void ray_begin(const DScene &sc, WaveLDS *w, const rt
     w->thr[slot] = (prune && t0 < 1E9) ? t0 * RT_PRUNE_SLACK : __builtin_huge_val();
 }
 
-/* the mesh hit of one ray, and Scene::intersect's choice between it and the sphere hit */
-__device__ __forceinline__ void ray_end(const DScene &sc, WaveLDS *w, int slot, const RayQ &q, HitRec &h) {
-    if (!q.active) return;
+/* The mesh hit of one ray, and Scene::intersect's choice between it and the sphere hit. After a traversal of the
+ * filter tree (own) the winner is first checked against the reference's own tree: the reference reaches a
+ * triangle iff the box test passes for its leaf and every box above it (raytracer.cpp:644-665), those boxes
+ * contain the leaf's box coordinate by coordinate, and the slab test is monotone in the box (each of its
+ * operations is), so "the leaf's box is certainly hit" settles all of them. Anything less - a grazed or flat
+ * leaf box, a hit without a triangle - returns true: the ray has to be traced again on the reference's tree. */
+__device__ __forceinline__ bool ray_end(const DScene &sc, WaveLDS *w, int slot, const RayQ &q, bool own, HitRec &h) {
+    if (!q.active) return false;
     const double tm = __longlong_as_double((long long)w->best_t[slot]);
     const int32_t pos = w->best_pos[slot];
     if (pos != INT32_MAX) {
         const bool phantom = pos >= RT_PHANTOM_BASE; /* the mesh reported a hit at t = 1E9 without a triangle */
+        if (own) {
+            if (phantom) return true;
+            const float *lb = sc.leaf_box32 + (size_t)sc.tri_leaf[pos] * 6;
+            RayK k;
+            k.iu = mk(w->ray[6][slot], w->ray[7][slot], w->ray[8][slot]);
+            k.nc = mk(w->ray[9][slot], w->ray[10][slot], w->ray[11][slot]);
+            k.tol = fabs(w->tol[slot]);
+            bool hit, unsure;
+            double tlo;
+            box_fast(Box6{(double)lb[0], (double)lb[1], (double)lb[2], (double)lb[3], (double)lb[4], (double)lb[5]}, k, hit, unsure, tlo);
+            if (!hit) return true;
+        }
         const int32_t mi2 = phantom ? pos - RT_PHANTOM_BASE : sc.tris[pos].mesh;
         const double tmm = phantom ? 1E9 : tm;
         const int32_t oid = sc.meshes[mi2].object_id;
@@ -414,6 +440,7 @@ __device__ __forceinline__ void ray_end(const DScene &sc, WaveLDS *w, int slot, 
             if (!phantom) (void)tri_test(sc, (uint32_t)pos, q.C, q.u, h.beta, h.gamma, lt); /* alpha, beta, gamma of the winner (:683-685) */
         }
     }
+    return false;
 }
 
 /* the mesh root box of one ray (raytracer.cpp:644); k and thr are the ray's constants as read at the start of the feed */
@@ -445,14 +472,26 @@ __device__ __forceinline__ RayK ray_k_from_lds(const WaveLDS *w, int slot) {
 /* Scene::intersect, raytracer.cpp:930-951, for up to two rays per lane (slots lane and 64 + lane). Called by all
  * 64 lanes together; active rays get their closest hit. */
 template <bool CNT>
-__device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w, const rt_sphere *sph, const RootRec *roots, const RayQ &qa, const RayQ &qb,
+__device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w, const rt_sphere *sph, const RootRec *roots, const RayQ &qa0, const RayQ &qb0,
                                                    bool prune, HitRec &ha, HitRec &hb, Cnt &cnt) {
     const int lane = lane_id();
     uint64_t st0 = 0;
-    if (CNT) { st0 = RT_STAMP(); cnt.queries++; cnt.query_lanes += (uint64_t)(__popcll(__ballot(qa.active)) + __popcll(__ballot(qb.active))); }
+    if (CNT) { st0 = RT_STAMP(); cnt.queries++; cnt.query_lanes += (uint64_t)(__popcll(__ballot(qa0.active)) + __popcll(__ballot(qb0.active))); }
+    RayQ qa = qa0, qb = qb0;
+    /* First on the filter tree (one tree over all meshes; not for the counted variant or RT_F_NO_PRUNE, which
+     * reproduce the reference's traversal); the rays whose winner could not be confirmed go round again on the
+     * reference's trees. */
+    bool own = !CNT && prune && sc.own_rec32 != nullptr;
+    HitRec kept_a = {}, kept_b = {};
+    bool kept = false, redo_a = false, redo_b = false;
+  for (;;) {
     ray_begin<CNT>(sc, w, sph, lane, qa, prune, ha, cnt);
     ray_begin<CNT>(sc, w, sph, RT_WAVE + lane, qb, prune, hb, cnt);
     if (sc.n_meshes == 0) return;
+    const NodeRec32 *const recs = own ? sc.own_rec32 : sc.rec32;
+    const rt_tri *const tri_base = own ? sc.own_tris : sc.tris;
+    const uint32_t n_recs = own ? sc.n_own_nodes : sc.n_nodes_total;
+    const int n_feed = own ? 1 : sc.n_meshes;
 
     int n_nodes = 0, n_leaves = 0; /* wave-uniform stack heights */
     int mi = 0;
@@ -461,7 +500,17 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
          * next mesh is fed whenever fewer than RT_FEED_BELOW node items are pending, so the traversals of
          * the meshes share their steps, and a root is already tested against the distance of the hits
          * found so far. */
-        if (mi < sc.n_meshes && n_nodes < RT_FEED_BELOW && n_leaves <= RT_WAVE) {
+        if (own && mi == 0) { /* the filter tree has no root box: every active ray starts at record 0 */
+            mi = 1;
+            const unsigned long long ba = __ballot(qa.active), bb = __ballot(qb.active);
+            const int ca = __popcll(ba);
+            const uint32_t ninf = __float_as_uint(-__builtin_huge_valf());
+            if (qa.active) w->node[rank_in(ba)] = make_uint2((uint32_t)lane << RT_NODE_BITS, ninf);
+            if (qb.active) w->node[ca + rank_in(bb)] = make_uint2((uint32_t)(RT_WAVE + lane) << RT_NODE_BITS, ninf);
+            n_nodes = ca + __popcll(bb);
+            wave_sync();
+        }
+        if (mi < n_feed && n_nodes < RT_FEED_BELOW && n_leaves <= RT_WAVE) {
             const RayK ka = ray_k_from_lds(w, lane), kb = ray_k_from_lds(w, RT_WAVE + lane);
             const double thr_a = w->thr[lane], thr_b = w->thr[RT_WAVE + lane]; /* as of now: thresholds only fall */
             do {
@@ -490,7 +539,7 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
                     }
                     n_leaves = uni(n_leaves + ca + __popcll(bb));
                 }
-            } while (mi < sc.n_meshes && n_nodes < RT_FEED_BELOW && n_leaves <= RT_WAVE);
+            } while (mi < n_feed && n_nodes < RT_FEED_BELOW && n_leaves <= RT_WAVE);
             wave_sync();
             if (CNT) { uint64_t t = RT_STAMP(); cnt.cyc_roots += t - st0; st0 = t; }
         }
@@ -545,7 +594,7 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
                 }
                 /* all coordinate loads and the ray's LDS reads are issued before anything is waited for:
                  * unconditional (a lane without a triangle reads triangle 0), fenced, then pinned */
-                Tri3 tv = tri_load(sc, ok ? tri : 0u);
+                Tri3 tv = tri_load(tri_base, ok ? tri : 0u);
                 V3 rc = mk(w->ray[0][rl], w->ray[1][rl], w->ray[2][rl]);
                 V3 ru = mk(w->ray[3][rl], w->ray[4][rl], w->ray[5][rl]);
                 asm volatile("" ::: "memory");
@@ -562,7 +611,7 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
                         /* raytracer.cpp:689-690: has_inter is set, t stays 1E9 and P, N, colour stay as the caller
                          * initialised them. Remembered as the lowest such mesh; any triangle below 1E9 overrides it. */
                         acc = false;
-                        atomicMin(&w->best_pos[rl], RT_PHANTOM_BASE + sc.tris[tri].mesh);
+                        atomicMin(&w->best_pos[rl], RT_PHANTOM_BASE + (own ? 0 : sc.tris[tri].mesh));
                     }
                 }
                 if (__ballot(acc) != 0ull) {
@@ -583,7 +632,7 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
                         }
                     }
                     wave_sync();
-                    if (mine) atomicMin(&w->best_pos[rl], (int32_t)tri);
+                    if (mine) atomicMin(&w->best_pos[rl], own ? tv.id : (int32_t)tri); /* position in the reference's order */
                 }
                 wave_sync();
                 if (CNT) { uint64_t t = RT_STAMP(); cnt.cyc_leaf += t - st0; st0 = t; cnt.leaf_steps++; cnt.leaf_lanes += (uint64_t)k; }
@@ -603,12 +652,12 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
                 wave_sync();
                 const int rl = (int)(it.x >> RT_NODE_BITS);
                 uint32_t rec = it.x & RT_LOW_MASK;
-                if (have && rec >= sc.n_nodes_total) { /* never fetch outside the arrays */
+                if (have && rec >= n_recs) { /* never fetch outside the arrays */
                     have = false;
                     atomicOr(sc.overflow, 2);
                 }
                 if (!have) rec = 0;
-                const float4 *rp = reinterpret_cast<const float4 *>(sc.rec32 + rec);
+                const float4 *rp = reinterpret_cast<const float4 *>(recs + rec);
                 const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
                 const double thr = w->thr[rl];
                 RayK rk;
@@ -616,7 +665,7 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
                 rk.nc = mk(w->ray[9][rl], w->ray[10][rl], w->ray[11][rl]);
                 rk.tol = fabs(w->tol[rl]);
                 have = have && !((double)__uint_as_float(it.y) > thr); /* fallen behind the threshold since it was pushed */
-                const bool ext = rec >= sc.n_ref_nodes; /* a filter of this implementation, not a record of the reference */
+                const bool ext = own || rec >= sc.n_ref_nodes; /* a filter of this implementation, not a record of the reference */
                 if (CNT && have && !ext) { cnt.nodes++; cnt.box_tests += 2; }
                 int32_t L = __float_as_int(q3.x), R = __float_as_int(q3.y);
                 const int32_t nL = __float_as_int(q3.z), nR = __float_as_int(q3.w);
@@ -672,9 +721,21 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
             }
         }
     }
-    ray_end(sc, w, lane, qa, ha);
-    ray_end(sc, w, RT_WAVE + lane, qb, hb);
+    const bool da = ray_end(sc, w, lane, qa, own, ha);
+    const bool db = ray_end(sc, w, RT_WAVE + lane, qb, own, hb);
     wave_sync();
+    if (!own || __ballot(da || db) == 0ull) break;
+    /* second round, on the reference's trees, for the unconfirmed rays only; the others keep their answers */
+    own = false;
+    kept_a = ha; kept_b = hb;
+    kept = true; redo_a = da; redo_b = db;
+    qa.active = da;
+    qb.active = db;
+  }
+    if (kept) {
+        if (!redo_a) ha = kept_a;
+        if (!redo_b) hb = kept_b;
+    }
     if (CNT) cnt.cyc_finish += RT_STAMP() - st0;
 }
 

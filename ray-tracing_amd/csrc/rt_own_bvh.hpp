@@ -1,0 +1,204 @@
+/*
+ * rt_own_bvh.hpp - host-side builder of the filter tree.
+ *
+ * The reference's BVH (raytracer.cpp:244-291) decides which triangles a ray may hit; its quality is poor
+ * (one tree per mesh, median cuts, leaves of up to hundreds of triangles). The traversal therefore runs on
+ * a second tree built here over ALL triangles of the scene - binned surface-area cuts, leaves of at most
+ * four triangles, triangles copied into this tree's own order - and uses it only to find candidate hits:
+ * a ray is kept out of a box just when it certainly misses it. Whether the reference would have reached
+ * the winning triangle is then checked on the reference's own leaf box (rt_device.hip.h: ray_end).
+ */
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "rt_amd.h"
+#include "rt_device.hip.h"
+
+namespace rtown {
+
+struct Bounds {
+    double lo[3], hi[3];
+    void reset() {
+        for (int a = 0; a < 3; a++) { lo[a] = HUGE_VAL; hi[a] = -HUGE_VAL; }
+    }
+    void grow(const Bounds &b) {
+        for (int a = 0; a < 3; a++) {
+            if (b.lo[a] < lo[a]) lo[a] = b.lo[a];
+            if (b.hi[a] > hi[a]) hi[a] = b.hi[a];
+        }
+    }
+    double half_area() const {
+        const double x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+        return x * y + y * z + z * x;
+    }
+};
+
+struct Built {
+    std::vector<rtd::NodeRec32> nodes; /* record 0 is the root; children have larger indices */
+    std::vector<int32_t> order;        /* position in this tree's triangle array -> position in the caller's array */
+    int depth = 0;
+    bool ok = false;                   /* false: the scene has a non-finite coordinate or no triangle; no tree */
+};
+
+static inline void box_to_float(const Bounds &b, float *box) { /* rounded outwards */
+    for (int a = 0; a < 3; a++) {
+        box[a] = nextafterf((float)b.lo[a], -HUGE_VALF);
+        box[3 + a] = nextafterf((float)b.hi[a], HUGE_VALF);
+    }
+}
+
+static const int kBins = 16;
+static const int kLeaf = 4;
+static const int kSahDepth = 40; /* below this depth ranges are halved by count, which bounds the depth */
+
+inline Built build(const rt_tri *tris, int64_t n) {
+    Built out;
+    if (n <= 0) return out;
+    std::vector<Bounds> tb((size_t)n);
+    std::vector<double> cen((size_t)n * 3);
+    for (int64_t k = 0; k < n; k++) {
+        Bounds &b = tb[(size_t)k];
+        b.reset();
+        for (int a = 0; a < 3; a++) {
+            const double v[3] = {tris[k].A[a], tris[k].A[a] + tris[k].e1[a], tris[k].A[a] + tris[k].e2[a]};
+            for (int q = 0; q < 3; q++) {
+                if (!std::isfinite(v[q])) return out;
+                if (v[q] < b.lo[a]) b.lo[a] = v[q];
+                if (v[q] > b.hi[a]) b.hi[a] = v[q];
+            }
+            cen[(size_t)k * 3 + a] = 0.5 * (b.lo[a] + b.hi[a]);
+        }
+    }
+    std::vector<int32_t> idx((size_t)n);
+    for (int64_t k = 0; k < n; k++) idx[(size_t)k] = (int32_t)k;
+
+    struct Job {
+        int64_t node; /* record that holds this range as child `side`, or -1 for the root range */
+        int side;
+        int64_t first, count;
+        int depth;
+    };
+    auto range_bounds = [&](int64_t first, int64_t count) {
+        Bounds b;
+        b.reset();
+        for (int64_t k = first; k < first + count; k++) b.grow(tb[(size_t)idx[(size_t)k]]);
+        return b;
+    };
+    std::vector<Job> jobs;
+    jobs.push_back(Job{-1, 0, 0, n, 1});
+    if (n <= kLeaf) { /* a tree needs one record: both children are leaves (the right one may be empty) */
+        rtd::NodeRec32 r;
+        const int64_t nl = (n + 1) / 2;
+        box_to_float(range_bounds(0, nl), r.boxL);
+        r.L = 0; r.nL = (int32_t)nl;
+        if (n - nl > 0) { box_to_float(range_bounds(nl, n - nl), r.boxR); r.R = (int32_t)nl; r.nR = (int32_t)(n - nl); }
+        else { for (int a = 0; a < 3; a++) { r.boxR[a] = HUGE_VALF; r.boxR[3 + a] = -HUGE_VALF; } r.R = 0; r.nR = 1; } /* inverted box: certainly missed */
+        out.nodes.push_back(r);
+        out.order = idx;
+        out.depth = 1;
+        out.ok = true;
+        return out;
+    }
+    for (size_t q = 0; q < jobs.size(); q++) { /* breadth-first: a child's index is larger than its parent's */
+        const Job jb = jobs[q];
+        /* choose the cut of [first, first + count) */
+        int64_t nl = jb.count / 2;
+        bool sorted = false;
+        if (jb.depth <= kSahDepth) {
+            Bounds cb;
+            cb.reset();
+            for (int64_t k = jb.first; k < jb.first + jb.count; k++)
+                for (int a = 0; a < 3; a++) {
+                    const double c = cen[(size_t)idx[(size_t)k] * 3 + a];
+                    if (c < cb.lo[a]) cb.lo[a] = c;
+                    if (c > cb.hi[a]) cb.hi[a] = c;
+                }
+            double best = HUGE_VAL;
+            int best_axis = -1, best_bin = 0;
+            for (int a = 0; a < 3; a++) {
+                const double ext = cb.hi[a] - cb.lo[a];
+                if (!(ext > 0)) continue;
+                Bounds bb[kBins];
+                int64_t bc[kBins];
+                for (int b = 0; b < kBins; b++) { bb[b].reset(); bc[b] = 0; }
+                const double scale = kBins / ext;
+                for (int64_t k = jb.first; k < jb.first + jb.count; k++) {
+                    const int32_t t = idx[(size_t)k];
+                    int b = (int)((cen[(size_t)t * 3 + a] - cb.lo[a]) * scale);
+                    if (b >= kBins) b = kBins - 1;
+                    if (b < 0) b = 0;
+                    bb[b].grow(tb[(size_t)t]);
+                    bc[b]++;
+                }
+                double ra[kBins];
+                Bounds acc;
+                acc.reset();
+                int64_t cnt = 0;
+                for (int b = kBins - 1; b >= 1; b--) { acc.grow(bb[b]); cnt += bc[b]; ra[b] = cnt ? acc.half_area() * (double)cnt : 0; }
+                acc.reset();
+                cnt = 0;
+                for (int b = 0; b < kBins - 1; b++) {
+                    acc.grow(bb[b]);
+                    cnt += bc[b];
+                    if (cnt == 0 || cnt == jb.count) continue;
+                    const double cost = acc.half_area() * (double)cnt + ra[b + 1];
+                    if (cost < best) { best = cost; best_axis = a; best_bin = b; }
+                }
+            }
+            if (best_axis >= 0) {
+                const double ext = cb.hi[best_axis] - cb.lo[best_axis], scale = kBins / ext, lo = cb.lo[best_axis];
+                int32_t *beg = idx.data() + jb.first, *end = beg + jb.count;
+                int32_t *mid = std::partition(beg, end, [&](int32_t t) {
+                    int b = (int)((cen[(size_t)t * 3 + best_axis] - lo) * scale);
+                    if (b >= kBins) b = kBins - 1;
+                    if (b < 0) b = 0;
+                    return b <= best_bin;
+                });
+                nl = mid - beg;
+                sorted = nl > 0 && nl < jb.count;
+            }
+        }
+        if (!sorted) { /* all centroids coincide, or too deep: halve the range along its longest centroid axis */
+            nl = jb.count / 2;
+            int axis = 0;
+            {
+                Bounds cb;
+                cb.reset();
+                for (int64_t k = jb.first; k < jb.first + jb.count; k++)
+                    for (int a = 0; a < 3; a++) {
+                        const double c = cen[(size_t)idx[(size_t)k] * 3 + a];
+                        if (c < cb.lo[a]) cb.lo[a] = c;
+                        if (c > cb.hi[a]) cb.hi[a] = c;
+                    }
+                for (int a = 1; a < 3; a++)
+                    if (cb.hi[a] - cb.lo[a] > cb.hi[axis] - cb.lo[axis]) axis = a;
+            }
+            std::nth_element(idx.begin() + jb.first, idx.begin() + jb.first + nl, idx.begin() + jb.first + jb.count,
+                             [&](int32_t x, int32_t y) { return cen[(size_t)x * 3 + axis] < cen[(size_t)y * 3 + axis]; });
+        }
+        const int64_t nr = jb.count - nl;
+        const int64_t id = (int64_t)out.nodes.size();
+        rtd::NodeRec32 r;
+        box_to_float(range_bounds(jb.first, nl), r.boxL);
+        box_to_float(range_bounds(jb.first + nl, nr), r.boxR);
+        r.L = (int32_t)jb.first; r.nL = (int32_t)nl;
+        r.R = (int32_t)(jb.first + nl); r.nR = (int32_t)nr;
+        out.nodes.push_back(r);
+        if (jb.node >= 0) {
+            rtd::NodeRec32 &pr = out.nodes[(size_t)jb.node];
+            if (jb.side == 0) { pr.L = (int32_t)id; pr.nL = 0; } else { pr.R = (int32_t)id; pr.nR = 0; }
+        }
+        if (jb.depth > out.depth) out.depth = jb.depth;
+        if (nl > kLeaf) jobs.push_back(Job{id, 0, jb.first, nl, jb.depth + 1});
+        if (nr > kLeaf) jobs.push_back(Job{id, 1, jb.first + nl, nr, jb.depth + 1});
+    }
+    out.order = idx;
+    out.ok = true;
+    return out;
+}
+
+} // namespace rtown
