@@ -481,7 +481,11 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
     /* First on the filter tree (one tree over all meshes; not for the counted variant or RT_F_NO_PRUNE, which
      * reproduce the reference's traversal); the rays whose winner could not be confirmed go round again on the
      * reference's trees. */
+#ifdef RT_DIAG_OWN /* diagnostic build: the counted variant also runs on the filter tree (its counters then differ from the reference's) */
+    bool own = prune && sc.own_rec32 != nullptr;
+#else
     bool own = !CNT && prune && sc.own_rec32 != nullptr;
+#endif
     HitRec kept_a = {}, kept_b = {};
     bool kept = false, redo_a = false, redo_b = false;
   for (;;) {
@@ -725,6 +729,7 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
     const bool db = ray_end(sc, w, RT_WAVE + lane, qb, own, hb);
     wave_sync();
     if (!own || __ballot(da || db) == 0ull) break;
+    if (CNT) { cnt.dbg[6] += (uint64_t)(__popcll(__ballot(da)) + __popcll(__ballot(db))); cnt.dbg[7]++; }
     /* second round, on the reference's trees, for the unconfirmed rays only; the others keep their answers */
     own = false;
     kept_a = ha; kept_b = hb;
