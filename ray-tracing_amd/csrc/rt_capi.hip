@@ -494,12 +494,12 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
                 bool covered = true;
                 for (int64_t k = 0; k < s->n_tris; k++) covered = covered && tri_leaf[(size_t)k] >= 0;
                 if (covered) { /* a triangle outside every leaf is never reached by the reference: such a scene keeps to its trees */
-                    if ((rc = upload_array(c, own.nodes.data(), own.nodes.size(), &d.own_rec32))) return rc;
+                    if ((rc = upload_array(c, own.wide.data(), own.wide.size(), &d.own_rec4))) return rc;
                     if ((rc = upload_array(c, otris.data(), otris.size(), &d.own_tris))) return rc;
                     if ((rc = upload_array(c, tri_leaf.data(), tri_leaf.size(), &d.tri_leaf))) return rc;
                     if ((rc = upload_array(c, leaf_box.data(), leaf_box.size(), &d.leaf_box32))) return rc;
-                    d.n_own_nodes = (uint32_t)own.nodes.size();
-                    if (own.depth > ext_depth + max_depth) own_depth = own.depth;
+                    d.n_own_nodes = (uint32_t)own.wide.size();
+                    own_depth = 3 * own.wide_depth + 2; /* stack entries the depth-first tail of a wide traversal can add */
                     HIPCHK(c, hipStreamSynchronize(c->stream));
                 }
             }

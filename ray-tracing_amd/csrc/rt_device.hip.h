@@ -42,7 +42,7 @@ namespace rtd {
 #define RT_NODE_SOFT 512
 #endif          /* node-item stack height up to which 64 items are popped per step */
 #ifndef RT_LEAF_CAP
-#define RT_LEAF_CAP 256           /* leaf-item stack entries */
+#define RT_LEAF_CAP 320           /* leaf-item stack entries */
 #endif
 #ifndef RT_LEAF_TRIGGER
 #define RT_LEAF_TRIGGER 64        /* pending leaf items that make the next pool step a triangle step */
@@ -55,7 +55,7 @@ namespace rtd {
 #define RT_EXT_LEAF 4             /* reference leaves with more triangles than this get extension records down to this size */
 #endif
 static_assert(RT_FEED_BELOW + 2 * RT_WAVE <= RT_NODE_SOFT, "a fed mesh adds up to 128 node items on top of RT_FEED_BELOW - 1");
-static_assert(RT_LEAF_CAP >= 3 * RT_WAVE, "a node step adds up to 128 leaf items and runs only when 128 slots are free; a fed mesh adds up to 128 on top of 64");
+static_assert(RT_LEAF_CAP >= 5 * RT_WAVE, "a node step adds up to 256 leaf items (filter tree: four children) and runs only when 256 slots are free; a fed mesh adds up to 128 on top of 64");
 #define RT_PHANTOM_BASE (1 << 30)  /* best_pos values from here on: "mesh (value - base) reports a hit without a triangle" */
 
 /* what the root phase needs of a mesh: the root box (raytracer.cpp:644) and where the tree starts */
@@ -82,6 +82,16 @@ struct NodeRec32 {
     int32_t L, R, nL, nR;
 };
 
+/* Record of the filter tree: four children, boxes in float rounded outwards. child: RT_CHILD_EMPTY, or a leaf
+ * (bit 31 set, bits 30-28 = triangle count - 1, bits 27-0 = first triangle in the filter tree's order), or the
+ * index of another record. */
+#define RT_CHILD_EMPTY 0xFFFFFFFFu
+struct NodeRec4 {
+    float box[4][6];
+    uint32_t child[4];
+    uint32_t pad[4];
+};
+
 struct DScene {
     const rt_sphere *spheres;
     const RootRec *roots;
@@ -89,7 +99,7 @@ struct DScene {
     const NodeHalf *halves;   /* 2 per BVH record */
     const NodeRec32 *rec32;   /* 1 per BVH record, boxes in float */
     /* the filter tree over all triangles of the scene (rt_own_bvh.hpp); null when it could not be built */
-    const NodeRec32 *own_rec32;
+    const NodeRec4 *own_rec4;
     const rt_tri *own_tris;   /* triangles in the filter tree's order; orig_id holds the position in `tris` */
     const int32_t *tri_leaf;  /* by triangle position: index of the reference leaf that holds it */
     const float *leaf_box32;  /* 6 floats per reference leaf: its box rounded to float (to nearest) */
@@ -482,9 +492,9 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
      * reproduce the reference's traversal); the rays whose winner could not be confirmed go round again on the
      * reference's trees. */
 #ifdef RT_DIAG_OWN /* diagnostic build: the counted variant also runs on the filter tree (its counters then differ from the reference's) */
-    bool own = prune && sc.own_rec32 != nullptr;
+    bool own = prune && sc.own_rec4 != nullptr;
 #else
-    bool own = !CNT && prune && sc.own_rec32 != nullptr;
+    bool own = !CNT && prune && sc.own_rec4 != nullptr;
 #endif
     HitRec kept_a = {}, kept_b = {};
     bool kept = false, redo_a = false, redo_b = false;
@@ -492,7 +502,7 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
     ray_begin<CNT>(sc, w, sph, lane, qa, prune, ha, cnt);
     ray_begin<CNT>(sc, w, sph, RT_WAVE + lane, qb, prune, hb, cnt);
     if (sc.n_meshes == 0) return;
-    const NodeRec32 *const recs = own ? sc.own_rec32 : sc.rec32;
+    const NodeRec32 *const recs = sc.rec32;
     const rt_tri *const tri_base = own ? sc.own_tris : sc.tris;
     const uint32_t n_recs = own ? sc.n_own_nodes : sc.n_nodes_total;
     const int n_feed = own ? 1 : sc.n_meshes;
@@ -550,7 +560,7 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
         if (n_nodes + n_leaves == 0) break; /* then every mesh has been fed: the feed runs whenever the pool is empty */
         /* one pool step: up to 64 items */
         {
-            const bool do_leaf = (n_leaves >= RT_LEAF_TRIGGER) || (n_nodes == 0) || (n_leaves + 2 * RT_WAVE > RT_LEAF_CAP);
+            const bool do_leaf = (n_leaves >= RT_LEAF_TRIGGER) || (n_nodes == 0) || (n_leaves + (own ? 4 : 2) * RT_WAVE > RT_LEAF_CAP);
             if (do_leaf) {
                 /* 64 triangles per step whichever leaves they sit in: the top m <= 64 leaf items are
                  * (first, count) ranges; a prefix sum of the counts gives every item its slots, slot s (=
@@ -640,6 +650,80 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
                 }
                 wave_sync();
                 if (CNT) { uint64_t t = RT_STAMP(); cnt.cyc_leaf += t - st0; st0 = t; cnt.leaf_steps++; cnt.leaf_lanes += (uint64_t)k; }
+            } else if (own) {
+                /* Filter tree: up to 64 four-child records per step, one per lane. A child is pushed unless the
+                 * ray certainly misses its box or the box starts beyond the ray's threshold. A step pops k
+                 * records and pushes at most 4 k, so k is held to a third of the room below RT_NODE_SOFT; above
+                 * it one record per step (depth-first: three more entries per level at most). */
+                int k = n_nodes < RT_WAVE ? n_nodes : RT_WAVE;
+                const int room = (RT_NODE_SOFT - n_nodes) / 3;
+                if (k > room) k = room > 1 ? room : 1;
+                bool have = lane < k;
+                const uint2 it = w->node[have ? n_nodes - 1 - lane : 0];
+                n_nodes -= k;
+                wave_sync();
+                const int rl = (int)(it.x >> RT_NODE_BITS);
+                uint32_t rec = it.x & RT_LOW_MASK;
+                if (have && rec >= n_recs) { /* never fetch outside the arrays */
+                    have = false;
+                    atomicOr(sc.overflow, 2);
+                }
+                if (!have) rec = 0;
+                const float4 *rp = reinterpret_cast<const float4 *>(sc.own_rec4 + rec);
+                const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3], q4 = rp[4], q5 = rp[5];
+                const uint4 ch = *reinterpret_cast<const uint4 *>(rp + 6);
+                const double thr = w->thr[rl];
+                /* The filter only ever needs "certainly missed", so it runs in float: slab parameter fma(b, iu, nc) with
+                 * iu, nc rounded to float differs from the real value by < 3 * 2^-24 M = 1.8e-7 M (M as in
+                 * ray_constants); the boxes are rounded outwards already. tol = 3.2 x the double test's 1.3e-7 M. */
+                const float iux = (float)w->ray[6][rl], iuy = (float)w->ray[7][rl], iuz = (float)w->ray[8][rl];
+                const float ncx = (float)w->ray[9][rl], ncy = (float)w->ray[10][rl], ncz = (float)w->ray[11][rl];
+                const float tolf = (float)(fabs(w->tol[rl]) * 3.2); /* NaN stays NaN: then nothing is ever certain */
+                float thrf = (float)thr;
+                thrf = __builtin_fmaf(__builtin_fabsf(thrf), 0x1p-22f, thrf) + 0x1p-125f; /* not below thr */
+                have = have && !((double)__uint_as_float(it.y) > thr); /* fallen behind the threshold since it was pushed */
+                const float bx[24] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w,
+                                      q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w};
+                const uint32_t code[4] = {ch.x, ch.y, ch.z, ch.w};
+                bool pn[4], pl[4];
+                float f[4];
+                int cn = 0, cl = 0;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const float t1x = __builtin_fmaf(bx[6 * c], iux, ncx), t2x = __builtin_fmaf(bx[6 * c + 3], iux, ncx);
+                    const float t1y = __builtin_fmaf(bx[6 * c + 1], iuy, ncy), t2y = __builtin_fmaf(bx[6 * c + 4], iuy, ncy);
+                    const float t1z = __builtin_fmaf(bx[6 * c + 2], iuz, ncz), t2z = __builtin_fmaf(bx[6 * c + 5], iuz, ncz);
+                    const float tMax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
+                    const float tMin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
+                    const bool miss = (tMax - tMin < -tolf) || (tMax < -tolf);
+                    const float tlo = tMin - tolf;
+                    const bool go = have && code[c] != RT_CHILD_EMPTY && !miss && !(tlo > thrf);
+                    pn[c] = go && !(code[c] >> 31);
+                    pl[c] = go && (code[c] >> 31);
+                    f[c] = __builtin_fmaf(-__builtin_fabsf(tlo), 0x1p-22f, tlo) - 0x1p-125f;
+                    cn += pn[c] ? 1 : 0;
+                    cl += pl[c] ? 1 : 0;
+                }
+                const int in_n = wave_scan_add(cn), in_l = wave_scan_add(cl);
+                const int tot_n = __builtin_amdgcn_readlane(in_n, 63), tot_l = __builtin_amdgcn_readlane(in_l, 63);
+                if (n_nodes + tot_n > sc.node_cap || n_leaves + tot_l > RT_LEAF_CAP) { /* cannot happen for a validated scene; never write past the stacks */
+                    if (lane == 0) atomicOr(sc.overflow, 1);
+                } else {
+                    int jn = n_nodes + in_n - cn, jl = n_leaves + in_l - cl;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        if (pn[c]) { w->node[jn] = make_uint2(code[c] | ((uint32_t)rl << RT_NODE_BITS), __float_as_uint(f[c])); jn++; }
+                        if (pl[c]) {
+                            w->leaf[jl] = make_uint2(code[c] & 0x0FFFFFFFu, (((code[c] >> 28) & 7u) + 1u) | ((uint32_t)rl << RT_NODE_BITS));
+                            w->leaf_t[jl] = f[c];
+                            jl++;
+                        }
+                    }
+                    n_nodes = uni(n_nodes + tot_n);
+                    n_leaves = uni(n_leaves + tot_l);
+                }
+                wave_sync();
+                if (CNT) { uint64_t t = RT_STAMP(); cnt.cyc_node += t - st0; st0 = t; cnt.node_steps++; cnt.node_lanes += (uint64_t)k; }
             } else {
                 /* Up to 64 BVH records per step, one per lane: both child boxes are tested (raytracer.cpp:656-665)
                  * and the children that are hit are pushed. 64 records are popped while the stack is below
@@ -669,7 +753,7 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
                 rk.nc = mk(w->ray[9][rl], w->ray[10][rl], w->ray[11][rl]);
                 rk.tol = fabs(w->tol[rl]);
                 have = have && !((double)__uint_as_float(it.y) > thr); /* fallen behind the threshold since it was pushed */
-                const bool ext = own || rec >= sc.n_ref_nodes; /* a filter of this implementation, not a record of the reference */
+                const bool ext = rec >= sc.n_ref_nodes; /* a filter of this implementation, not a record of the reference */
                 if (CNT && have && !ext) { cnt.nodes++; cnt.box_tests += 2; }
                 int32_t L = __float_as_int(q3.x), R = __float_as_int(q3.y);
                 const int32_t nL = __float_as_int(q3.z), nR = __float_as_int(q3.w);

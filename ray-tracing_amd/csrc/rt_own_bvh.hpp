@@ -38,11 +38,15 @@ struct Bounds {
 };
 
 struct Built {
-    std::vector<rtd::NodeRec32> nodes; /* record 0 is the root; children have larger indices */
+    std::vector<rtd::NodeRec32> nodes; /* binary tree: record 0 is the root; children have larger indices */
+    std::vector<rtd::NodeRec4> wide;   /* the same tree with four children per record (collapse() below) */
+    int wide_depth = 0;
     std::vector<int32_t> order;        /* position in this tree's triangle array -> position in the caller's array */
     int depth = 0;
     bool ok = false;                   /* false: the scene has a non-finite coordinate or no triangle; no tree */
 };
+
+inline void collapse(Built &b);
 
 static inline void box_to_float(const Bounds &b, float *box) { /* rounded outwards */
     for (int a = 0; a < 3; a++) {
@@ -101,6 +105,7 @@ inline Built build(const rt_tri *tris, int64_t n) {
         out.order = idx;
         out.depth = 1;
         out.ok = true;
+        collapse(out);
         return out;
     }
     for (size_t q = 0; q < jobs.size(); q++) { /* breadth-first: a child's index is larger than its parent's */
@@ -198,7 +203,66 @@ inline Built build(const rt_tri *tris, int64_t n) {
     }
     out.order = idx;
     out.ok = true;
+    collapse(out);
     return out;
+}
+
+/* Four children per record: a record starts with the two children of a binary node and, while it has room,
+ * replaces the inner child with the largest box by that child's own two children. Halves the number of levels,
+ * and with it the number of dependent steps of a traversal. */
+inline void collapse(Built &b) {
+    struct Cand { float box[6]; int32_t ref, count; };
+    struct Job { int64_t bin; int64_t parent; int slot; int depth; };
+    auto area = [](const float *x) {
+        const double dx = (double)x[3] - x[0], dy = (double)x[4] - x[1], dz = (double)x[5] - x[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    std::vector<Job> jobs;
+    jobs.push_back(Job{0, -1, 0, 1});
+    for (size_t q = 0; q < jobs.size(); q++) {
+        const Job jb = jobs[q];
+        Cand c[4];
+        int n = 2;
+        {
+            const rtd::NodeRec32 &r = b.nodes[(size_t)jb.bin];
+            for (int a = 0; a < 6; a++) { c[0].box[a] = r.boxL[a]; c[1].box[a] = r.boxR[a]; }
+            c[0].ref = r.L; c[0].count = r.nL;
+            c[1].ref = r.R; c[1].count = r.nR;
+        }
+        while (n < 4) {
+            int pick = -1;
+            double best = -1;
+            for (int k = 0; k < n; k++)
+                if (c[k].count == 0 && area(c[k].box) > best) { best = area(c[k].box); pick = k; }
+            if (pick < 0) break;
+            const rtd::NodeRec32 &r = b.nodes[(size_t)c[pick].ref];
+            Cand l, rr;
+            for (int a = 0; a < 6; a++) { l.box[a] = r.boxL[a]; rr.box[a] = r.boxR[a]; }
+            l.ref = r.L; l.count = r.nL;
+            rr.ref = r.R; rr.count = r.nR;
+            c[pick] = l;
+            c[n++] = rr;
+        }
+        const int64_t id = (int64_t)b.wide.size();
+        rtd::NodeRec4 w;
+        for (int k = 0; k < 4; k++) {
+            if (k < n) {
+                for (int a = 0; a < 6; a++) w.box[k][a] = c[k].box[a];
+                if (c[k].count > 0 && !(c[k].box[0] <= c[k].box[3])) w.child[k] = RT_CHILD_EMPTY; /* the inverted box of an empty leaf */
+                else if (c[k].count > 0) w.child[k] = 0x80000000u | ((uint32_t)(c[k].count - 1) << 28) | (uint32_t)c[k].ref;
+                else w.child[k] = 0; /* filled in when the child's record gets its index */
+            } else {
+                for (int a = 0; a < 3; a++) { w.box[k][a] = HUGE_VALF; w.box[k][3 + a] = -HUGE_VALF; }
+                w.child[k] = RT_CHILD_EMPTY;
+            }
+            w.pad[k] = 0;
+        }
+        b.wide.push_back(w);
+        if (jb.parent >= 0) b.wide[(size_t)jb.parent].child[jb.slot] = (uint32_t)id;
+        if (jb.depth > b.wide_depth) b.wide_depth = jb.depth;
+        for (int k = 0; k < n; k++)
+            if (c[k].count == 0) jobs.push_back(Job{c[k].ref, id, k, jb.depth + 1});
+    }
 }
 
 } // namespace rtown
