@@ -210,7 +210,7 @@ static int check_overflow(rt_ctx *c) {
     if (flag) {
         (void)hipMemsetAsync(c->d_overflow, 0, sizeof(int), c->stream);
         return fail(c, RT_E_DEVICE, "traversal pool %s: results of the last launch are incomplete",
-                    (flag & 2) ? "produced an index outside the scene arrays" : "overflow");
+                    (flag & 8) ? "did not terminate" : (flag & 2) ? "produced an index outside the scene arrays" : "overflow");
     }
     return RT_OK;
 }

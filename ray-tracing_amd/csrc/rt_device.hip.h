@@ -51,6 +51,7 @@ namespace rtd {
 #define RT_NODE_BITS 25           /* record-index / leaf-count bits in a pool item (the ray slot takes the top 7) */
 #define RT_LOW_MASK ((1u << RT_NODE_BITS) - 1u)
 #define RT_MAX_DEPTH 60
+#define RT_STEP_LIMIT (1u << 24)  /* pool steps of one query after which it is given up (and reported) */
 #ifndef RT_EXT_LEAF
 #define RT_EXT_LEAF 4             /* reference leaves with more triangles than this get extension records down to this size */
 #endif
@@ -509,6 +510,7 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
 
     int n_nodes = 0, n_leaves = 0; /* wave-uniform stack heights */
     int mi = 0;
+    unsigned steps = 0;
     for (;;) {
         /* Root boxes (raytracer.cpp:644): every lane for its own rays; roots that pass enter the pool. The
          * next mesh is fed whenever fewer than RT_FEED_BELOW node items are pending, so the traversals of
@@ -558,6 +560,10 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
             if (CNT) { uint64_t t = RT_STAMP(); cnt.cyc_roots += t - st0; st0 = t; }
         }
         if (n_nodes + n_leaves == 0) break; /* then every mesh has been fed: the feed runs whenever the pool is empty */
+        if (++steps > RT_STEP_LIMIT) { /* a traversal visits every record and triangle at most once per ray: far more steps mean corrupt items */
+            if (lane == 0) atomicOr(sc.overflow, 8);
+            break;
+        }
         /* one pool step: up to 64 items */
         {
             const bool do_leaf = (n_leaves >= RT_LEAF_TRIGGER) || (n_nodes == 0) || (n_leaves + (own ? 4 : 2) * RT_WAVE > RT_LEAF_CAP);
@@ -704,8 +710,10 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
                     cn += pn[c] ? 1 : 0;
                     cl += pl[c] ? 1 : 0;
                 }
-                const int in_n = wave_scan_add(cn), in_l = wave_scan_add(cl);
-                const int tot_n = __builtin_amdgcn_readlane(in_n, 63), tot_l = __builtin_amdgcn_readlane(in_l, 63);
+                const int in_both = wave_scan_add(cn | (cl << 16)); /* both prefix sums at once: each stays below 2^16 */
+                const int in_n = in_both & 0xFFFF, in_l = in_both >> 16;
+                const int tot_both = __builtin_amdgcn_readlane(in_both, 63);
+                const int tot_n = tot_both & 0xFFFF, tot_l = tot_both >> 16;
                 if (n_nodes + tot_n > sc.node_cap || n_leaves + tot_l > RT_LEAF_CAP) { /* cannot happen for a validated scene; never write past the stacks */
                     if (lane == 0) atomicOr(sc.overflow, 1);
                 } else {
