@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP64_VECTOR_TFLOPS = 78.6   # MI355X vector FP64 = half the 157.3 TFLOP/s FP32 vector peak
 PEAK_HBM_GBS = 8000.0
-PROFILE_PREFIX = "r1_v7_ext_records_"  # rocprofv3 summaries of this round's kernel under profiles/
+PROFILE_PREFIX = "r1_v8_filter_tree_"  # rocprofv3 summaries of this round's kernel under profiles/
 
 
 def algorithmic_flops(c, n_spheres):
