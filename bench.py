@@ -181,6 +181,10 @@ def main():
                                         % (PROFILE_PREFIX, bytes_per_path * paths_per_launch))
         except (OSError, KeyError, IndexError, ValueError, ZeroDivisionError):
             pass
+        import ctypes
+        sz = (ctypes.c_uint64 * 4)()
+        rta.lib.rt_debug_scene_sizes(r._h, sz)  # device bytes with every derived array; record counts
+        sizes = [int(x) for x in sz]
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import bindings as ob
@@ -206,7 +210,8 @@ def main():
                                       "extrapolates to %.2f s on this many GPUs" % (info["n_tris"], info["n_nodes"], W, H, args.spp_step,
                                                                                       1000.0 * W * H / (value * 1e6)),
                           "spp_per_step": args.spp_step, "parallelism": "spp-sharded x%d + RCCL reduce(sum) of the f64 accumulator" % world,
-                          "scene_bytes_hbm": info["bytes"], "setup_s": round(setup_s, 2)},
+                          "scene_bytes_hbm": info["bytes"], "scene_bytes_device": sizes[0], "traversal_records": sizes[1],
+                          "filter_tree_records": sizes[2], "setup_s": round(setup_s, 2)},
                "rays_per_s": round(value * 1e6 * c["rays"] / c["paths"], 1),
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out))

@@ -153,6 +153,7 @@ struct rt_ctx {
     bool light_ok = false;
     DScene sc{};
     std::vector<void *> scene_allocs;
+    size_t scene_bytes = 0; /* device bytes of the uploaded scene, every derived array included */
     size_t lds_bytes = 0;
     /* own accumulator */
     double *accum = nullptr;
@@ -187,6 +188,7 @@ static int fail(rt_ctx *c, int code, const char *fmt, ...) {
 static void free_scene(rt_ctx *c) {
     for (void *p : c->scene_allocs) (void)hipFree(p);
     c->scene_allocs.clear();
+    c->scene_bytes = 0;
     c->have_scene = false;
 }
 
@@ -197,6 +199,7 @@ static int upload_array(rt_ctx *c, const T *host, size_t n, const T **dev_out) {
     void *d = nullptr;
     if (hipMalloc(&d, n * sizeof(T)) != hipSuccess) return fail(c, RT_E_NOMEM, "hipMalloc of %zu bytes failed", n * sizeof(T));
     c->scene_allocs.push_back(d);
+    c->scene_bytes += n * sizeof(T);
     HIPCHK(c, hipMemcpyAsync(d, host, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
     *dev_out = static_cast<const T *>(d);
     return RT_OK;
@@ -777,6 +780,17 @@ int rt_debug_occupancy(rt_ctx *c, int *blocks_per_cu, int *lds_bytes) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, rt_render_kernel<false>, RT_BLOCK, c->lds_bytes));
     *lds_bytes = (int)c->lds_bytes;
+    return RT_OK;
+}
+
+/* not part of the public header: device bytes of the uploaded scene, traversal records (reference + extension), filter-tree
+ * records, LDS stack entries per wave (tools/ and bench.py's report only) */
+int rt_debug_scene_sizes(rt_ctx *c, uint64_t *out4) {
+    if (!c || !out4 || !c->have_scene) return RT_E_INVALID;
+    out4[0] = c->scene_bytes;
+    out4[1] = c->sc.n_nodes_total;
+    out4[2] = c->sc.n_own_nodes;
+    out4[3] = (uint64_t)c->sc.node_cap;
     return RT_OK;
 }
 
