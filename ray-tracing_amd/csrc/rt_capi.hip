@@ -30,7 +30,7 @@ using namespace rtd;
 
 /* LDS of the wave; sphere lists of up to RT_LDS_SPHERES_MAX entries are staged behind the node stack
  * (every ray tests every sphere: raytracer.cpp:934-938), longer lists are read from global memory
- * with wave-uniform addresses. */
+ * with wave-uniform addresses. Mesh root records are read with wave-uniform addresses too (scalar loads). */
 __device__ __forceinline__ WaveLDS *wave_setup(const DScene &sc, unsigned char *lds_raw, const rt_sphere **sph, const RootRec **roots) {
     WaveLDS *w = reinterpret_cast<WaveLDS *>(lds_raw);
     unsigned char *p = const_cast<unsigned char *>(reinterpret_cast<const unsigned char *>(lds_spheres(w, sc.node_cap)));
@@ -42,14 +42,6 @@ __device__ __forceinline__ WaveLDS *wave_setup(const DScene &sc, unsigned char *
         uint4 *d16 = reinterpret_cast<uint4 *>(p);
         for (int q = threadIdx.x; q < n16; q += RT_BLOCK) d16[q] = src[q];
         *sph = reinterpret_cast<const rt_sphere *>(p);
-        p += (size_t)sc.n_spheres * sizeof(rt_sphere);
-    }
-    if (sc.n_meshes <= RT_LDS_ROOTS_MAX) {
-        const int n16 = sc.n_meshes * (int)(sizeof(RootRec) / 16);
-        const uint4 *src = reinterpret_cast<const uint4 *>(sc.roots);
-        uint4 *d16 = reinterpret_cast<uint4 *>(p);
-        for (int q = threadIdx.x; q < n16; q += RT_BLOCK) d16[q] = src[q];
-        *roots = reinterpret_cast<const RootRec *>(p);
     }
     wave_sync();
     return w;
@@ -63,7 +55,11 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_kernel(DScene
     const RootRec *roots;
     WaveLDS *w = wave_setup(sc, lds_raw, &sph, &roots);
     Cnt cnt = {};
-    render_persistent<CNT>(sc, w, sph, roots, ra, k0, nk, accum, next_slot, n_slots, cnt);
+    /* what the queries' inner loops use stays in the kernel arguments (scalar registers); everything else is read from a
+     * copy in LDS where it is needed */
+    if (threadIdx.x == 0) { w->sc = sc; w->ra = ra; }
+    wave_sync();
+    render_persistent<CNT>(sc, w->sc, w, sph, roots, w->ra, k0, nk, accum, next_slot, n_slots, cnt);
     if (CNT) flush_counters(cnt, counters);
 }
 
@@ -77,7 +73,7 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_sample_kernel(DScene sc, RenderAr
     const bool live = q < n;
     Cnt cnt = {};
     const int i = live ? ijk[3 * q] : 0, j = live ? ijk[3 * q + 1] : 0, k = live ? ijk[3 * q + 2] : 0;
-    V3 a = trace_pixel<false>(sc, w, sph, roots, ra, live, i, j, k, 1, cnt);
+    V3 a = trace_pixel<false>(sc, sc, w, sph, roots, ra, live, i, j, k, 1, cnt);
     if (live) {
         out[3 * q] = a.x;
         out[3 * q + 1] = a.y;
@@ -100,7 +96,7 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_intersect_kernel(DScene sc, const
     Cnt cnt = {};
     HitRec h2;
     const RayQ qa = RayQ{live, C, u, 1E10, false}, qb = RayQ{false, C, u, 1E10, false};
-    scene_closest_wave<false>(sc, w, sph, roots, qa, qb, prune != 0, h, h2, cnt);
+    scene_closest_wave<false>(sc, sc, w, sph, roots, qa, qb, prune != 0, h, h2, cnt);
     const bool ok = h.obj != INT32_MAX;
     if (!live) return;
     obj_id[q] = ok ? h.obj : -1;
@@ -548,8 +544,7 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
     d.n_tris_total = (uint32_t)s->n_tris;
     d.n_ref_nodes = (uint32_t)s->n_nodes;
     c->sc = d;
-    c->lds_bytes = sizeof(WaveLDS) + (size_t)d.node_cap * 8 + 16 + ((s->n_spheres <= RT_LDS_SPHERES_MAX) ? (size_t)s->n_spheres * sizeof(rt_sphere) : 0) +
-                   ((s->n_meshes <= RT_LDS_ROOTS_MAX) ? (size_t)s->n_meshes * sizeof(RootRec) : 0);
+    c->lds_bytes = sizeof(WaveLDS) + (size_t)d.node_cap * 8 + 16 + ((s->n_spheres <= RT_LDS_SPHERES_MAX) ? (size_t)s->n_spheres * sizeof(rt_sphere) : 0);
     if (c->lds_bytes > 64 * 1024) return fail(c, RT_E_INVALID, "rt_upload_scene: per-wave LDS of %zu bytes exceeds 64 KiB", c->lds_bytes);
     /* persistent waves of the render kernel that stay resident on one CU with this scene's LDS use */
     {

@@ -34,12 +34,11 @@ namespace rtd {
 
 #define RT_WAVE 64
 #define RT_LDS_SPHERES_MAX 64     /* sphere lists up to this size are staged in LDS */
-#define RT_LDS_ROOTS_MAX 32       /* mesh root records (box + root) up to this many are staged in LDS */
 #ifndef RT_FEED_BELOW
-#define RT_FEED_BELOW 384         /* mesh roots are fed to the pool while fewer node items than this are pending (measured: the more the better) */
+#define RT_FEED_BELOW 256         /* mesh roots are fed to the pool while fewer node items than this are pending (measured: the more the better) */
 #endif
 #ifndef RT_NODE_SOFT
-#define RT_NODE_SOFT 512
+#define RT_NODE_SOFT 384
 #endif          /* node-item stack height up to which 64 items are popped per step */
 #ifndef RT_LEAF_CAP
 #define RT_LEAF_CAP 320           /* leaf-item stack entries */
@@ -220,8 +219,8 @@ __device__ __forceinline__ RayK ray_constants(const DScene &sc, V3 C, V3 u) {
     k.nc = mk(-(C.x * k.iu.x), -(C.y * k.iu.y), -(C.z * k.iu.z));
     const double ax = fabs(k.iu.x), ay = fabs(k.iu.y), az = fabs(k.iu.z);
     const double mx = (sc.bmax[0] + fabs(C.x)) * ax, my = (sc.bmax[1] + fabs(C.y)) * ay, mz = (sc.bmax[2] + fabs(C.z)) * az;
-    const bool ok = (sc.bmax[0] < 1e30) && (sc.bmax[1] < 1e30) && (sc.bmax[2] < 1e30) && (mx < 1e30) && (my < 1e30) && (mz < 1e30) && (ax > 1e-200) && (ay > 1e-200) && (az > 1e-200) &&
-                    (ax < 1e200) && (ay < 1e200) && (az < 1e200) && (fabs(C.x) < 1e200) && (fabs(C.y) < 1e200) && (fabs(C.z) < 1e200);
+    const bool ok = (sc.bmax[0] < 1e30) && (sc.bmax[1] < 1e30) && (sc.bmax[2] < 1e30) && (mx < 1e30) && (my < 1e30) && (mz < 1e30) && (ax > 1e-25) && (ay > 1e-25) && (az > 1e-25) &&
+                    (ax < 1e25) && (ay < 1e25) && (az < 1e25) && (fabs(C.x) < 1e200) && (fabs(C.y) < 1e200) && (fabs(C.z) < 1e200);
     const double m = fmax(mx, fmax(my, mz));
     k.tol = ok ? 1.3e-7 * m : __builtin_nan("");
     return k;
@@ -248,6 +247,35 @@ __device__ __forceinline__ void box_fast(const Box6 &b, const RayK &k, bool &hit
 __device__ __forceinline__ float lower_float(double t) {
     const float f = (float)t;
     return __builtin_fmaf(-__builtin_fabsf(f), 0x1p-22f, f) - 0x1p-125f;
+}
+__device__ __forceinline__ float lower_float(float f) { return __builtin_fmaf(-__builtin_fabsf(f), 0x1p-22f, f) - 0x1p-125f; }
+/* a float that is certainly not below t */
+__device__ __forceinline__ float upper_float(double t) {
+    const float f = (float)t;
+    return __builtin_fmaf(__builtin_fabsf(f), 0x1p-22f, f) + 0x1p-125f;
+}
+
+/* The traversal's form of the same test, in single precision: iu, nc rounded to float, slab parameter
+ * fmaf(b', iu, nc). Against the real value that is off by at most 2^-24 (3 |b iu| + 2 |C iu|) <= 3 * 2^-24 M = 1.8e-7 M
+ * (rounding of b, iu, nc and of the result; ray_constants keeps |iu| and M inside the normal float range or marks the
+ * ray), so tMax - tMin carries 3.6e-7 M and RT_TOLF_SCALE * tol = 4.2e-7 M decides safely. Only what the fast test
+ * leaves undecided reaches the FP64 boxes and the reference's divisions. */
+#define RT_TOLF_SCALE 3.2
+struct RayKf {
+    float iux, iuy, iuz, ncx, ncy, ncz;
+    float tol; /* >= 0, or NaN */
+};
+__device__ __forceinline__ void box_fast_f(float lx, float ly, float lz, float hx, float hy, float hz, const RayKf &k, bool &hit, bool &unsure, float &tlo) {
+    const float t1x = __builtin_fmaf(lx, k.iux, k.ncx), t2x = __builtin_fmaf(hx, k.iux, k.ncx);
+    const float t1y = __builtin_fmaf(ly, k.iuy, k.ncy), t2y = __builtin_fmaf(hy, k.iuy, k.ncy);
+    const float t1z = __builtin_fmaf(lz, k.iuz, k.ncz), t2z = __builtin_fmaf(hz, k.iuz, k.ncz);
+    const float tMax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
+    const float tMin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
+    const float d = tMax - tMin;
+    hit = (d > k.tol) && (tMax > k.tol);
+    const bool miss = (d < -k.tol) || (tMax < -k.tol);
+    unsure = !(hit || miss);
+    tlo = tMin - k.tol;
 }
 
 /* triangle test, raytracer.cpp:673-687 */
@@ -292,15 +320,29 @@ struct HitRec {
 };
 
 /* ---- per-wave LDS ------------------------------------------------------------------------- */
+struct RenderArgs {
+    rt_camera cam;
+    rt_params p;
+    uint64_t seed_mixed; /* mix64(seed + golden) */
+    int32_t j0, i0, j1, i1;
+};
+
 struct WaveLDS {
-    double ray[12][RT_RAY_SLOTS];         /* C, u, 1/u, -(C/u) of each ray */
-    double tol[RT_RAY_SLOTS];             /* |tol|: below this the fast box test does not decide (NaN: never). The sign bit is set
-                                             when the caller only asks whether something is hit before tmax */
+    double ray[6][RT_RAY_SLOTS];          /* C, u of each ray */
+    float rayf[6][RT_RAY_SLOTS];          /* 1/u, -(C/u) rounded to float: the traversal's box test */
+    float tolf[RT_RAY_SLOTS];             /* |tolf|: below this the single-precision box test does not decide (NaN: never). The sign
+                                             bit is set when the caller only asks whether something is hit before tmax */
+    float thrf[RT_RAY_SLOTS];             /* not below the distance beyond which nothing can change the ray's result */
     unsigned long long best_t[RT_RAY_SLOTS]; /* bits of the smallest accepted triangle t (> 0, so the bit order is the value order) */
-    double thr[RT_RAY_SLOTS];             /* distance beyond which nothing can change the ray's result */
     int32_t best_pos[RT_RAY_SLOTS];       /* lowest triangle position among those with that t */
     int32_t mark[RT_WAVE];                /* triangle step: slot -> leaf item that starts there, or -1 */
     int32_t ex[RT_WAVE];                  /* triangle step: first slot of each leaf item */
+    DScene sc;                            /* the render kernel's copy of its scene and frame arguments: what is used between the
+                                             queries is read from here, so that it does not occupy scalar registers during them */
+    RenderArgs ra;
+#ifdef RT_LDS_PAD /* diagnostic: fewer resident waves per CU */
+    double lds_pad[RT_LDS_PAD / 8];
+#endif
     uint2 leaf[RT_LEAF_CAP];              /* leaf items: x = first triangle, y = count | ray slot << 25 */
     float leaf_t[RT_LEAF_CAP];            /* entry parameter of the leaf's box, rounded down */
     uint2 node[1];                        /* node items: x = record index | ray slot << 25, y = entry parameter (float bits, rounded
@@ -378,7 +420,8 @@ __device__ __forceinline__ void ray_begin(const DScene &sc, WaveLDS *w, const rt
     if (!q.active) return;
     const V3 C = q.C, u = q.u;
     if (CNT) cnt.rays++;
-    for (int s = 0; s < sc.n_spheres; s++) {
+    const int n_sph = uni(sc.n_spheres); /* wave-uniform also when read from LDS */
+    for (int s = 0; s < n_sph; s++) {
         V3 O = ld3(sph[s].O);
         double R = sph[s].R;
         int32_t oid = sph[s].object_id;
@@ -408,14 +451,15 @@ __device__ __forceinline__ void ray_begin(const DScene &sc, WaveLDS *w, const rt
     const RayK k = ray_constants(sc, C, u);
     w->ray[0][slot] = C.x; w->ray[1][slot] = C.y; w->ray[2][slot] = C.z;
     w->ray[3][slot] = u.x; w->ray[4][slot] = u.y; w->ray[5][slot] = u.z;
-    w->ray[6][slot] = k.iu.x; w->ray[7][slot] = k.iu.y; w->ray[8][slot] = k.iu.z;
-    w->ray[9][slot] = k.nc.x; w->ray[10][slot] = k.nc.y; w->ray[11][slot] = k.nc.z;
-    w->tol[slot] = (q.anyhit && prune) ? -k.tol : k.tol; /* the sign bit of a NaN is kept too */
+    w->rayf[0][slot] = (float)k.iu.x; w->rayf[1][slot] = (float)k.iu.y; w->rayf[2][slot] = (float)k.iu.z;
+    w->rayf[3][slot] = (float)k.nc.x; w->rayf[4][slot] = (float)k.nc.y; w->rayf[5][slot] = (float)k.nc.z;
+    const float tf = (float)(k.tol * RT_TOLF_SCALE);
+    w->tolf[slot] = (q.anyhit && prune) ? -tf : tf; /* the sign bit of a NaN is kept too */
     w->best_t[slot] = (unsigned long long)__double_as_longlong(t0);
     w->best_pos[slot] = INT32_MAX;
     /* While nothing closer than 1E9 is known, nothing may be skipped by distance: a triangle hit at or beyond
      * 1E9 still makes TriangleMesh::intersect return true (raytracer.cpp:689 sets has_inter before :690 compares). */
-    w->thr[slot] = (prune && t0 < 1E9) ? t0 * RT_PRUNE_SLACK : __builtin_huge_val();
+    w->thrf[slot] = (prune && t0 < 1E9) ? upper_float(t0 * RT_PRUNE_SLACK) : __builtin_huge_valf();
 }
 
 /* The mesh hit of one ray, and Scene::intersect's choice between it and the sphere hit. After a traversal of the
@@ -433,10 +477,7 @@ __device__ __forceinline__ bool ray_end(const DScene &sc, WaveLDS *w, int slot, 
         if (own) {
             if (phantom) return true;
             const float *lb = sc.leaf_box32 + (size_t)sc.tri_leaf[pos] * 6;
-            RayK k;
-            k.iu = mk(w->ray[6][slot], w->ray[7][slot], w->ray[8][slot]);
-            k.nc = mk(w->ray[9][slot], w->ray[10][slot], w->ray[11][slot]);
-            k.tol = fabs(w->tol[slot]);
+            const RayK k = ray_constants(sc, q.C, q.u); /* the double-precision form: as few rays as possible should go round again */
             bool hit, unsure;
             double tlo;
             box_fast(Box6{(double)lb[0], (double)lb[1], (double)lb[2], (double)lb[3], (double)lb[4], (double)lb[5]}, k, hit, unsure, tlo);
@@ -456,15 +497,15 @@ __device__ __forceinline__ bool ray_end(const DScene &sc, WaveLDS *w, int slot, 
 
 /* the mesh root box of one ray (raytracer.cpp:644); k and thr are the ray's constants as read at the start of the feed */
 template <bool CNT>
-__device__ __forceinline__ bool root_test(const DScene &sc, const RootRec &m, int mesh, const RayQ &q, const RayK &k, double thr, float &fn, Cnt &cnt) {
+__device__ __forceinline__ bool root_test(const DScene &sc, const RootRec &m, int mesh, const RayQ &q, const RayKf &k, float thr, float &fn, Cnt &cnt) {
     if (!q.active) return false;
     if (CNT) cnt.box_tests++;
     bool pass, unsure;
-    double tn;
-    box_fast(Box6{(double)m.box[0], (double)m.box[1], (double)m.box[2], (double)m.box[3], (double)m.box[4], (double)m.box[5]}, k, pass, unsure, tn);
+    float tn;
+    box_fast_f(m.box[0], m.box[1], m.box[2], m.box[3], m.box[4], m.box[5], k, pass, unsure, tn);
     if (__builtin_expect(unsure, 0)) {
         pass = box_hit_exact(sc.meshes[mesh].root_box, q.C.x, q.C.y, q.C.z, q.u.x, q.u.y, q.u.z);
-        tn = -__builtin_huge_val();
+        tn = -__builtin_huge_valf();
     }
     if (CNT && pass) cnt.mesh_calls++;
     fn = lower_float(tn);
@@ -472,18 +513,18 @@ __device__ __forceinline__ bool root_test(const DScene &sc, const RootRec &m, in
 }
 
 /* a ray's constants of the fast box test, back from the pool's tables */
-__device__ __forceinline__ RayK ray_k_from_lds(const WaveLDS *w, int slot) {
-    RayK k;
-    k.iu = mk(w->ray[6][slot], w->ray[7][slot], w->ray[8][slot]);
-    k.nc = mk(w->ray[9][slot], w->ray[10][slot], w->ray[11][slot]);
-    k.tol = fabs(w->tol[slot]);
+__device__ __forceinline__ RayKf ray_k_from_lds(const WaveLDS *w, int slot) {
+    RayKf k;
+    k.iux = w->rayf[0][slot]; k.iuy = w->rayf[1][slot]; k.iuz = w->rayf[2][slot];
+    k.ncx = w->rayf[3][slot]; k.ncy = w->rayf[4][slot]; k.ncz = w->rayf[5][slot];
+    k.tol = __builtin_fabsf(w->tolf[slot]);
     return k;
 }
 
 /* Scene::intersect, raytracer.cpp:930-951, for up to two rays per lane (slots lane and 64 + lane). Called by all
  * 64 lanes together; active rays get their closest hit. */
 template <bool CNT>
-__device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w, const rt_sphere *sph, const RootRec *roots, const RayQ &qa0, const RayQ &qb0,
+__device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScene &cold, WaveLDS *w, const rt_sphere *sph, const RootRec *roots, const RayQ &qa0, const RayQ &qb0,
                                                    bool prune, HitRec &ha, HitRec &hb, Cnt &cnt) {
     const int lane = lane_id();
     uint64_t st0 = 0;
@@ -500,8 +541,8 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
     HitRec kept_a = {}, kept_b = {};
     bool kept = false, redo_a = false, redo_b = false;
   for (;;) {
-    ray_begin<CNT>(sc, w, sph, lane, qa, prune, ha, cnt);
-    ray_begin<CNT>(sc, w, sph, RT_WAVE + lane, qb, prune, hb, cnt);
+    ray_begin<CNT>(cold, w, sph, lane, qa, prune, ha, cnt);
+    ray_begin<CNT>(cold, w, sph, RT_WAVE + lane, qb, prune, hb, cnt);
     if (sc.n_meshes == 0) return;
     const NodeRec32 *const recs = sc.rec32;
     const rt_tri *const tri_base = own ? sc.own_tris : sc.tris;
@@ -527,13 +568,13 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
             wave_sync();
         }
         if (mi < n_feed && n_nodes < RT_FEED_BELOW && n_leaves <= RT_WAVE) {
-            const RayK ka = ray_k_from_lds(w, lane), kb = ray_k_from_lds(w, RT_WAVE + lane);
-            const double thr_a = w->thr[lane], thr_b = w->thr[RT_WAVE + lane]; /* as of now: thresholds only fall */
+            const RayKf ka = ray_k_from_lds(w, lane), kb = ray_k_from_lds(w, RT_WAVE + lane);
+            const float thr_a = w->thrf[lane], thr_b = w->thrf[RT_WAVE + lane]; /* as of now: thresholds only fall */
             do {
                 const RootRec &m = roots[mi];
                 float fa = 0.f, fb = 0.f;
-                const bool pa = root_test<CNT>(sc, m, mi, qa, ka, thr_a, fa, cnt);
-                const bool pb = root_test<CNT>(sc, m, mi, qb, kb, thr_b, fb, cnt);
+                const bool pa = root_test<CNT>(cold, m, mi, qa, ka, thr_a, fa, cnt);
+                const bool pb = root_test<CNT>(cold, m, mi, qb, kb, thr_b, fb, cnt);
                 mi++;
                 const unsigned long long ba = __ballot(pa), bb = __ballot(pb);
                 if ((ba | bb) == 0ull) continue;
@@ -580,7 +621,7 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
                 if (lane < m) {
                     it = w->leaf[n_leaves - 1 - lane];
                     cntl = (int)(it.y & RT_LOW_MASK);
-                    if ((double)w->leaf_t[n_leaves - 1 - lane] > w->thr[it.y >> RT_NODE_BITS]) cntl = 0;
+                    if (w->leaf_t[n_leaves - 1 - lane] > w->thrf[it.y >> RT_NODE_BITS]) cntl = 0;
                 }
                 const int incl = wave_scan_add(cntl);
                 const int excl = incl - cntl;
@@ -648,7 +689,7 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
                         mine = (tb == cur);
                         if (mine && old > cur) { /* this lane lowered the minimum */
                             w->best_pos[rl] = INT32_MAX;
-                            if (prune) w->thr[rl] = (__double_as_longlong(w->tol[rl]) < 0) ? 0.0 : lt * RT_PRUNE_SLACK;
+                            if (prune) w->thrf[rl] = (__float_as_int(w->tolf[rl]) < 0) ? 0.f : upper_float(lt * RT_PRUNE_SLACK);
                         }
                     }
                     wave_sync();
@@ -678,16 +719,12 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
                 const float4 *rp = reinterpret_cast<const float4 *>(sc.own_rec4 + rec);
                 const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3], q4 = rp[4], q5 = rp[5];
                 const uint4 ch = *reinterpret_cast<const uint4 *>(rp + 6);
-                const double thr = w->thr[rl];
-                /* The filter only ever needs "certainly missed", so it runs in float: slab parameter fma(b, iu, nc) with
-                 * iu, nc rounded to float differs from the real value by < 3 * 2^-24 M = 1.8e-7 M (M as in
-                 * ray_constants); the boxes are rounded outwards already. tol = 3.2 x the double test's 1.3e-7 M. */
-                const float iux = (float)w->ray[6][rl], iuy = (float)w->ray[7][rl], iuz = (float)w->ray[8][rl];
-                const float ncx = (float)w->ray[9][rl], ncy = (float)w->ray[10][rl], ncz = (float)w->ray[11][rl];
-                const float tolf = (float)(fabs(w->tol[rl]) * 3.2); /* NaN stays NaN: then nothing is ever certain */
-                float thrf = (float)thr;
-                thrf = __builtin_fmaf(__builtin_fabsf(thrf), 0x1p-22f, thrf) + 0x1p-125f; /* not below thr */
-                have = have && !((double)__uint_as_float(it.y) > thr); /* fallen behind the threshold since it was pushed */
+                /* the filter only ever needs "certainly missed" (box_fast_f's miss); its boxes are rounded outwards */
+                const float thrf = w->thrf[rl];
+                const float iux = w->rayf[0][rl], iuy = w->rayf[1][rl], iuz = w->rayf[2][rl];
+                const float ncx = w->rayf[3][rl], ncy = w->rayf[4][rl], ncz = w->rayf[5][rl];
+                const float tolf = __builtin_fabsf(w->tolf[rl]); /* NaN: then nothing is ever certain */
+                have = have && !(__uint_as_float(it.y) > thrf); /* fallen behind the threshold since it was pushed */
                 const float bx[24] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w,
                                       q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w};
                 const uint32_t code[4] = {ch.x, ch.y, ch.z, ch.w};
@@ -755,31 +792,26 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
                 if (!have) rec = 0;
                 const float4 *rp = reinterpret_cast<const float4 *>(recs + rec);
                 const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
-                const double thr = w->thr[rl];
-                RayK rk;
-                rk.iu = mk(w->ray[6][rl], w->ray[7][rl], w->ray[8][rl]);
-                rk.nc = mk(w->ray[9][rl], w->ray[10][rl], w->ray[11][rl]);
-                rk.tol = fabs(w->tol[rl]);
-                have = have && !((double)__uint_as_float(it.y) > thr); /* fallen behind the threshold since it was pushed */
+                const float thr = w->thrf[rl];
+                const RayKf rk = ray_k_from_lds(w, rl);
+                have = have && !(__uint_as_float(it.y) > thr); /* fallen behind the threshold since it was pushed */
                 const bool ext = rec >= sc.n_ref_nodes; /* a filter of this implementation, not a record of the reference */
                 if (CNT && have && !ext) { cnt.nodes++; cnt.box_tests += 2; }
                 int32_t L = __float_as_int(q3.x), R = __float_as_int(q3.y);
                 const int32_t nL = __float_as_int(q3.z), nR = __float_as_int(q3.w);
-                const Box6 bl = Box6{(double)q0.x, (double)q0.y, (double)q0.z, (double)q0.w, (double)q1.x, (double)q1.y};
-                const Box6 br = Box6{(double)q1.z, (double)q1.w, (double)q2.x, (double)q2.y, (double)q2.z, (double)q2.w};
                 bool hl, hr, ul, ur;
-                double tl, tr;
-                box_fast(bl, rk, hl, ul, tl);
-                box_fast(br, rk, hr, ur, tr);
+                float tl, tr;
+                box_fast_f(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, rk, hl, ul, tl);
+                box_fast_f(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, rk, hr, ur, tr);
                 if (ext) { /* kept out only by a certain miss; with RT_F_NO_PRUNE every triangle the reference tests is tested */
                     hl = hl || ul || !prune;
                     hr = hr || ur || !prune;
-                    if (!prune) tl = tr = -__builtin_huge_val();
+                    if (!prune) tl = tr = -__builtin_huge_valf();
                 } else if (__builtin_expect(have && (ul || ur), 0)) { /* rare: the double boxes and true divisions, as the reference does them */
                     const double cx = w->ray[0][rl], cy = w->ray[1][rl], cz = w->ray[2][rl];
                     const double ux = w->ray[3][rl], uy = w->ray[4][rl], uz = w->ray[5][rl];
-                    if (ul) { hl = box_hit_exact(sc.halves[(size_t)rec * 2].box, cx, cy, cz, ux, uy, uz); tl = -__builtin_huge_val(); }
-                    if (ur) { hr = box_hit_exact(sc.halves[(size_t)rec * 2 + 1].box, cx, cy, cz, ux, uy, uz); tr = -__builtin_huge_val(); }
+                    if (ul) { hl = box_hit_exact(sc.halves[(size_t)rec * 2].box, cx, cy, cz, ux, uy, uz); tl = -__builtin_huge_valf(); }
+                    if (ur) { hr = box_hit_exact(sc.halves[(size_t)rec * 2 + 1].box, cx, cy, cz, ux, uy, uz); tr = -__builtin_huge_valf(); }
                 }
                 hl = have && hl && !(tl > thr);
                 hr = have && hr && !(tr > thr);
@@ -817,8 +849,8 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, WaveLDS *w,
             }
         }
     }
-    const bool da = ray_end(sc, w, lane, qa, own, ha);
-    const bool db = ray_end(sc, w, RT_WAVE + lane, qb, own, hb);
+    const bool da = ray_end(cold, w, lane, qa, own, ha);
+    const bool db = ray_end(cold, w, RT_WAVE + lane, qb, own, hb);
     wave_sync();
     if (!own || __ballot(da || db) == 0ull) break;
     if (CNT) { cnt.dbg[6] += (uint64_t)(__popcll(__ballot(da)) + __popcll(__ballot(db))); cnt.dbg[7]++; }
@@ -895,13 +927,6 @@ __device__ __forceinline__ V3 random_cos(double u1, double u2, V3 N) {
     V3 T2 = cross(N, T1);
     return add(add(smul(z, N), smul(x, T1)), smul(y, T2));
 }
-
-struct RenderArgs {
-    rt_camera cam;
-    rt_params p;
-    uint64_t seed_mixed; /* mix64(seed + golden) */
-    int32_t j0, i0, j1, i1;
-};
 
 /* State of one pixel's sample loop between two queries: the rays to trace next and what the recursion of
  * Scene::getColor would hold on its stack. A diffuse vertex leaves two rays, its shadow ray and the indirect
@@ -1099,7 +1124,7 @@ __device__ __forceinline__ void path_advance(const DScene &sc, const rt_sphere *
  * order (the k loop of raytracer.cpp:1464-1486). Called by all 64 lanes of the wave; lanes with
  * live == false only help in the pool. */
 template <bool CNT>
-__device__ __forceinline__ V3 trace_pixel(const DScene &sc, WaveLDS *w, const rt_sphere *sph, const RootRec *roots, const RenderArgs &ra, bool live, int i,
+__device__ __forceinline__ V3 trace_pixel(const DScene &sc, const DScene &cold, WaveLDS *w, const rt_sphere *sph, const RootRec *roots, const RenderArgs &ra, bool live, int i,
                                           int j, int k0, int nk, Cnt &cnt) {
     Path q;
     path_begin(q, k0, live);
@@ -1113,9 +1138,9 @@ __device__ __forceinline__ V3 trace_pixel(const DScene &sc, WaveLDS *w, const rt
         HitRec h, hs;
         const RayQ qa = RayQ{!q.finished && q.segment, q.rC, q.ru, 1E10, false};
         const RayQ qb = RayQ{!q.finished && q.shadow, q.shC, q.shU, q.sh_limit, true};
-        scene_closest_wave<CNT>(sc, w, sph, roots, qa, qb, !(ra.p.flags & RT_F_NO_PRUNE), h, hs, cnt);
+        scene_closest_wave<CNT>(sc, cold, w, sph, roots, qa, qb, !(ra.p.flags & RT_F_NO_PRUNE), h, hs, cnt);
         if (CNT) sp0 = RT_STAMP();
-        if (!q.finished) path_advance<CNT>(sc, sph, ra, q, h.obj != INT32_MAX, h, hs.obj != INT32_MAX, hs, cnt);
+        if (!q.finished) path_advance<CNT>(cold, sph, ra, q, h.obj != INT32_MAX, h, hs.obj != INT32_MAX, hs, cnt);
         if (CNT) cnt.cyc_shade += RT_STAMP() - sp0;
     }
     return q.acc;
@@ -1138,7 +1163,7 @@ __device__ __forceinline__ bool slot_pixel(const RenderArgs &ra, int64_t slot, i
  * sum and takes the next free slot. Because lanes re-fill independently, the wave's pool stays full until the
  * whole frame runs out of pixels, instead of idling while the longest of 64 fixed pixels finishes. */
 template <bool CNT>
-__device__ __forceinline__ void render_persistent(const DScene &sc, WaveLDS *w, const rt_sphere *sph, const RootRec *roots,
+__device__ __forceinline__ void render_persistent(const DScene &sc, const DScene &cold, WaveLDS *w, const rt_sphere *sph, const RootRec *roots,
                                                   const RenderArgs &ra, int k0, int nk, double *accum, int *next_slot, int n_slots,
                                                   Cnt &cnt) {
     Path q;
@@ -1188,9 +1213,9 @@ __device__ __forceinline__ void render_persistent(const DScene &sc, WaveLDS *w, 
         HitRec h, hs;
         const RayQ qa = RayQ{!q.finished && q.segment, q.rC, q.ru, 1E10, false};
         const RayQ qb = RayQ{!q.finished && q.shadow, q.shC, q.shU, q.sh_limit, true};
-        scene_closest_wave<CNT>(sc, w, sph, roots, qa, qb, !(ra.p.flags & RT_F_NO_PRUNE), h, hs, cnt);
+        scene_closest_wave<CNT>(sc, cold, w, sph, roots, qa, qb, !(ra.p.flags & RT_F_NO_PRUNE), h, hs, cnt);
         if (CNT) sp0 = RT_STAMP();
-        if (!q.finished) path_advance<CNT>(sc, sph, ra, q, h.obj != INT32_MAX, h, hs.obj != INT32_MAX, hs, cnt);
+        if (!q.finished) path_advance<CNT>(cold, sph, ra, q, h.obj != INT32_MAX, h, hs.obj != INT32_MAX, hs, cnt);
         if (CNT) cnt.cyc_shade += RT_STAMP() - sp0;
     }
 }

@@ -218,6 +218,24 @@ def test_stochastic_per_sample(gpu, rta, scenes, ob, name, kw):
     assert bad <= max(2, len(ijk) // 2000), (bad, len(ijk), np.sort(rel)[-5:])
 
 
+def test_many_spheres_and_one_big_mesh(gpu, rta, scenes, ob):
+    """cfg5 at reduced size: more spheres than the per-wave LDS staging holds (so they are read from
+    global memory) of all three materials, plus one mesh: hits bit-exact, per-sample radiance as above"""
+    W = 96
+    s, cam, flags, orc = _scene_pair(ob, scenes, scenes.stress, W=W, n_tris=60000, n_spheres=150)
+    assert s.flat_info()["n_spheres"] > 64
+    gpu.upload(s)
+    rays, _ = ob.primary_rays(cam, W, W)
+    g, o = gpu.intersect_rays(rays), orc.intersect_rays(rays)
+    assert (o["tri"] >= 0).sum() > 200 and len(np.unique(o["obj"])) > 20
+    _check_hits(g, o)
+    p = rta.make_params(W, W, 2, flags=flags)
+    ijk = np.array([(i, j, k) for i in range(0, W, 2) for j in range(0, W, 2) for k in range(2)], np.int32)
+    rel = _rel_err(gpu.sample_radiance(cam, p, ijk), orc.sample_radiance(cam, p, ijk))
+    bad = (rel > 1e-9).sum()
+    assert bad <= max(2, len(ijk) // 1000), (bad, len(ijk), np.sort(rel)[-5:])
+
+
 def test_render_equals_sum_of_samples(gpu, rta, scenes, ob):
     """rt_render adds samples k = spp_offset.. in order; rect and spp_offset sharding agree with the oracle"""
     W = 64
