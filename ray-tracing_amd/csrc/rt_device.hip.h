@@ -738,11 +738,11 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScen
                     const float t1z = __builtin_fmaf(bx[6 * c + 2], iuz, ncz), t2z = __builtin_fmaf(bx[6 * c + 5], iuz, ncz);
                     const float tMax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
                     const float tMin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
-                    const bool miss = (tMax - tMin < -tolf) || (tMax < -tolf);
+                    const bool miss = (tMax - tMin < -tolf) | (tMax < -tolf);
                     const float tlo = tMin - tolf;
-                    const bool go = have && code[c] != RT_CHILD_EMPTY && !miss && !(tlo > thrf);
-                    pn[c] = go && !(code[c] >> 31);
-                    pl[c] = go && (code[c] >> 31);
+                    const bool go = have & (code[c] != RT_CHILD_EMPTY) & !miss & !(tlo > thrf); /* no short cuts: straight-line code */
+                    pn[c] = go & !(code[c] >> 31);
+                    pl[c] = go & (bool)(code[c] >> 31);
                     f[c] = __builtin_fmaf(-__builtin_fabsf(tlo), 0x1p-22f, tlo) - 0x1p-125f;
                     cn += pn[c] ? 1 : 0;
                     cl += pl[c] ? 1 : 0;
