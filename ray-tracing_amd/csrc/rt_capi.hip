@@ -468,36 +468,44 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
                 if (nr > RT_EXT_LEAF) jobs.push_back(ExtJob{id, 1, jb.first + nl, nr, jb.depth + 1});
             }
         }
-        /* the filter tree over all triangles, and what confirms its winners: the reference leaf of every triangle */
+        /* The filter tree over the triangles of all meshes, and what confirms its winners: the reference leaf of every
+         * triangle. A leaf whose box has no thickness along an axis is never entered by the reference (tMax > tMin cannot
+         * hold, raytracer.cpp:184), so its triangles are left out of the filter tree: they cannot be part of any answer. */
         if (s->n_tris > 0) {
-            rtown::Built own = rtown::build(s->tris, s->n_tris);
-            if (own.ok && (int64_t)own.nodes.size() < (1LL << RT_NODE_BITS)) {
-                std::vector<rt_tri> otris((size_t)s->n_tris);
-                for (int64_t k = 0; k < s->n_tris; k++) {
-                    otris[(size_t)k] = s->tris[own.order[(size_t)k]];
-                    otris[(size_t)k].orig_id = own.order[(size_t)k]; /* position in the reference's order */
+            std::vector<int32_t> tri_leaf((size_t)s->n_tris, -1);
+            std::vector<float> leaf_box;
+            std::vector<char> leaf_flat;
+            auto add_leaf = [&](const double *box, int32_t first, int32_t count) {
+                const int32_t id = (int32_t)(leaf_box.size() / 6);
+                for (int a = 0; a < 6; a++) leaf_box.push_back((float)box[a]);
+                leaf_flat.push_back(box[0] == box[3] || box[1] == box[4] || box[2] == box[5]);
+                for (int32_t k = first; k < first + count; k++) tri_leaf[(size_t)k] = id;
+            };
+            for (int64_t k = 0; k < s->n_nodes; k++) {
+                if (s->nodes[k].nL > 0) add_leaf(s->nodes[k].boxL, s->nodes[k].L, s->nodes[k].nL);
+                if (s->nodes[k].nR > 0) add_leaf(s->nodes[k].boxR, s->nodes[k].R, s->nodes[k].nR);
+            }
+            for (int mi = 0; mi < s->n_meshes; mi++)
+                if (s->meshes[mi].root_count > 0) add_leaf(s->meshes[mi].root_box, s->meshes[mi].root, s->meshes[mi].root_count);
+            /* a triangle outside every leaf is never reached by the reference either */
+            std::vector<rt_tri> sub;
+            sub.reserve((size_t)s->n_tris);
+            for (int64_t k = 0; k < s->n_tris; k++)
+                if (tri_leaf[(size_t)k] >= 0 && !leaf_flat[(size_t)tri_leaf[(size_t)k]]) {
+                    sub.push_back(s->tris[k]);
+                    sub.back().orig_id = (int32_t)k; /* position in the reference's order */
                 }
-                std::vector<int32_t> tri_leaf((size_t)s->n_tris, -1);
-                std::vector<float> leaf_box;
-                auto add_leaf = [&](const double *box, int32_t first, int32_t count) {
-                    const int32_t id = (int32_t)(leaf_box.size() / 6);
-                    for (int a = 0; a < 6; a++) leaf_box.push_back((float)box[a]);
-                    for (int32_t k = first; k < first + count; k++) tri_leaf[(size_t)k] = id;
-                };
-                for (int64_t k = 0; k < s->n_nodes; k++) {
-                    if (s->nodes[k].nL > 0) add_leaf(s->nodes[k].boxL, s->nodes[k].L, s->nodes[k].nL);
-                    if (s->nodes[k].nR > 0) add_leaf(s->nodes[k].boxR, s->nodes[k].R, s->nodes[k].nR);
-                }
-                for (int mi = 0; mi < s->n_meshes; mi++)
-                    if (s->meshes[mi].root_count > 0) add_leaf(s->meshes[mi].root_box, s->meshes[mi].root, s->meshes[mi].root_count);
-                bool covered = true;
-                for (int64_t k = 0; k < s->n_tris; k++) covered = covered && tri_leaf[(size_t)k] >= 0;
-                if (covered) { /* a triangle outside every leaf is never reached by the reference: such a scene keeps to its trees */
+            if (!sub.empty()) {
+                rtown::Built own = rtown::build(sub.data(), (int64_t)sub.size());
+                if (own.ok && (int64_t)own.nodes.size() < (1LL << RT_NODE_BITS)) {
+                    std::vector<rt_tri> otris(sub.size());
+                    for (size_t k = 0; k < sub.size(); k++) otris[k] = sub[(size_t)own.order[k]];
                     if ((rc = upload_array(c, own.wide.data(), own.wide.size(), &d.own_rec4))) return rc;
                     if ((rc = upload_array(c, otris.data(), otris.size(), &d.own_tris))) return rc;
                     if ((rc = upload_array(c, tri_leaf.data(), tri_leaf.size(), &d.tri_leaf))) return rc;
                     if ((rc = upload_array(c, leaf_box.data(), leaf_box.size(), &d.leaf_box32))) return rc;
                     d.n_own_nodes = (uint32_t)own.wide.size();
+                    d.n_own_tris = (uint32_t)otris.size();
                     own_depth = 3 * own.wide_depth + 2; /* stack entries the depth-first tail of a wide traversal can add */
                     HIPCHK(c, hipStreamSynchronize(c->stream));
                 }

@@ -104,7 +104,7 @@ struct DScene {
     const int32_t *tri_leaf;  /* by triangle position: index of the reference leaf that holds it */
     const float *leaf_box32;  /* 6 floats per reference leaf: its box rounded to float (to nearest) */
     uint32_t n_own_nodes;
-    int32_t pad_own;
+    uint32_t n_own_tris;      /* triangles in own_tris: those the reference's traversal can reach */
     const rt_tri *tris;       /* by triangle position (80 bytes each: a leaf's triangles are contiguous) */
     const rt_tri_attr *attrs;
     const rt_texture *tex;
@@ -547,6 +547,7 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScen
     const NodeRec32 *const recs = sc.rec32;
     const rt_tri *const tri_base = own ? sc.own_tris : sc.tris;
     const uint32_t n_recs = own ? sc.n_own_nodes : sc.n_nodes_total;
+    const uint32_t n_tri_lim = own ? sc.n_own_tris : sc.n_tris_total;
     const int n_feed = own ? 1 : sc.n_meshes;
 
     int n_nodes = 0, n_leaves = 0; /* wave-uniform stack heights */
@@ -649,7 +650,7 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScen
                 bool acc = false;
                 double beta, gamma, lt = 0;
                 bool ok = have;
-                if (have && tri >= sc.n_tris_total) { /* never fetch outside the arrays */
+                if (have && tri >= n_tri_lim) { /* never fetch outside the arrays */
                     atomicOr(sc.overflow, 2);
                     ok = false;
                 }
