@@ -198,24 +198,31 @@ __device__ __noinline__ bool box_hit_exact(const double *b, double cx, double cy
     return tMax > tMin;
 }
 
-/* Per-ray constants of the fast box test: iu = 1/u, nc = -(C * iu), and the tolerance below which the
- * fast test does not decide. The slab parameter (b - C) / u of the reference is formed here as
- * fma(b', iu, nc), where b' is the box coordinate b rounded to float (|b' - b| <= 2^-24 |b|; mesh root
- * boxes are used unrounded). With T the real-number value and M = max over the axes of
- * (bmax + |C|) * |iu|:
- *   |fma(b', iu, nc) - T| <= 2^-24 |b iu| + 2^-53 (2 |T| + |C iu|) (1 + tiny),   |reference - T| <= 2^-53 * 2 |T| (1 + tiny),
+/* Per-ray constants of the fast box test: iu = 1/u (to 2^-45, rcp_near), nc = -(C * iu), and the tolerance below
+ * which the fast test does not decide. The slab parameter (b - C) / u of the reference is formed as
+ * fma(b', iu, nc), where b' is the box coordinate b rounded to float (|b' - b| <= 2^-24 |b|). With T the
+ * real-number value and M = max over the axes of (bmax + |C|) * |iu|:
+ *   |fma(b', iu, nc) - T| <= 2^-24 |b iu| + 2^-44 (|T| + |b iu| + |C iu|),   |reference - T| <= 2^-53 * 2 |T| (1 + tiny),
  * so the two differ by less than 6.0e-8 M; min and max do not enlarge a difference. tol = 1.3e-7 M
  * covers that twice over (the test compares tMax - tMin, which carries two such errors). Rays for which
  * the bound cannot be trusted (a zero, huge, tiny or non-finite direction component or origin, or a
  * scene whose boxes do not fit a float) get tol = NaN: no comparison with it holds and every one of
- * their boxes goes to the exact test. */
+ * their boxes goes to the exact test. This double-precision form confirms the filter tree's winners (ray_end);
+ * the traversal itself uses the single-precision form below. */
 struct RayK {
     V3 iu, nc;
     double tol;
 };
+/* 1/x to a relative error below 2^-45 (hardware estimate + one Newton step) instead of the ~35 instructions of a
+ * correctly rounded division: far inside the margins of the box tests. Zero, denormal and non-finite x give
+ * infinities or NaN, which ray_constants turns into tol = NaN. */
+__device__ __forceinline__ double rcp_near(double x) {
+    const double r = __builtin_amdgcn_rcp(x);
+    return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+}
 __device__ __forceinline__ RayK ray_constants(const DScene &sc, V3 C, V3 u) {
     RayK k;
-    k.iu = mk(1.0 / u.x, 1.0 / u.y, 1.0 / u.z);
+    k.iu = mk(rcp_near(u.x), rcp_near(u.y), rcp_near(u.z));
     k.nc = mk(-(C.x * k.iu.x), -(C.y * k.iu.y), -(C.z * k.iu.z));
     const double ax = fabs(k.iu.x), ay = fabs(k.iu.y), az = fabs(k.iu.z);
     const double mx = (sc.bmax[0] + fabs(C.x)) * ax, my = (sc.bmax[1] + fabs(C.y)) * ay, mz = (sc.bmax[2] + fabs(C.z)) * az;
@@ -543,6 +550,7 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScen
   for (;;) {
     ray_begin<CNT>(cold, w, sph, lane, qa, prune, ha, cnt);
     ray_begin<CNT>(cold, w, sph, RT_WAVE + lane, qb, prune, hb, cnt);
+    if (CNT) { const uint64_t t = RT_STAMP(); cnt.cyc_roots += t - st0; st0 = t; } /* spheres and ray constants count with the roots */
     if (sc.n_meshes == 0) return;
     const NodeRec32 *const recs = sc.rec32;
     const rt_tri *const tri_base = own ? sc.own_tris : sc.tris;
@@ -917,8 +925,10 @@ __device__ __forceinline__ void hit_surface(const DScene &sc, const rt_sphere *s
 
 /* random_cos, raytracer.cpp:112-138 */
 __device__ __forceinline__ V3 random_cos(double u1, double u2, V3 N) {
-    double x = cos(2 * RT_PI * u1) * sqrt(1 - u2);
-    double y = sin(2 * RT_PI * u1) * sqrt(1 - u2);
+    double sn, cs; /* one argument reduction for both (same values as separate calls) */
+    sincos(2 * RT_PI * u1, &sn, &cs);
+    double x = cs * sqrt(1 - u2);
+    double y = sn * sqrt(1 - u2);
     double z = sqrt(u2);
     V3 T1;
     if (N.x < N.y && N.x < N.z) T1 = mk(0, N.z, -N.y);
@@ -974,11 +984,14 @@ __device__ __forceinline__ void path_fresh(const RenderArgs &ra, Path &q, int i,
         q.rC = camC;
     } else { /* raytracer.cpp:1467-1483 */
         double u1 = rng_uniform(q.key, 0), u2 = rng_uniform(q.key, 1);
-        double x1 = cam.aa_sigma * cos(2 * RT_PI * u1) * sqrt(-2 * log(u2)),
-               x2 = cam.aa_sigma * sin(2 * RT_PI * u1) * sqrt(-2 * log(u2));
+        double s1, c1, s3, c3;
+        sincos(2 * RT_PI * u1, &s1, &c1);
+        double x1 = cam.aa_sigma * c1 * sqrt(-2 * log(u2)),
+               x2 = cam.aa_sigma * s1 * sqrt(-2 * log(u2));
         double u3 = rng_uniform(q.key, 2), u4 = rng_uniform(q.key, 3);
-        double x3 = cam.dof_sigma * cos(2 * RT_PI * u3) * sqrt(-2 * log(u4)),
-               x4 = cam.dof_sigma * sin(2 * RT_PI * u3) * sqrt(-2 * log(u4));
+        sincos(2 * RT_PI * u3, &s3, &c3);
+        double x3 = cam.dof_sigma * c3 * sqrt(-2 * log(u4)),
+               x4 = cam.dof_sigma * s3 * sqrt(-2 * log(u4));
         q.ctr = 4;
         V3 d = mk(j - p.W / 2 + x2 + 0.5, i - p.H / 2 + x1 + 0.5, cam.zdist);
         d = unit(d);
