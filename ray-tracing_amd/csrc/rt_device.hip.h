@@ -528,6 +528,60 @@ __device__ __forceinline__ RayKf ray_k_from_lds(const WaveLDS *w, int slot) {
     return k;
 }
 
+/* One record of the filter tree for ray slot rl: a child is pushed unless the ray certainly misses its box (box_fast_f's
+ * miss; the filter's boxes are rounded outwards) or the box starts beyond the ray's threshold. Called by all 64 lanes;
+ * lanes with have == false only take part in the prefix sum. item_t is the entry parameter the record was pushed with. */
+__device__ __forceinline__ void wide_children(const DScene &sc, WaveLDS *w, int lane, bool have, int rl, float item_t, const float4 &q0, const float4 &q1,
+                                              const float4 &q2, const float4 &q3, const float4 &q4, const float4 &q5, const uint4 &ch, int &n_nodes, int &n_leaves) {
+    const float thrf = w->thrf[rl];
+    const float iux = w->rayf[0][rl], iuy = w->rayf[1][rl], iuz = w->rayf[2][rl];
+    const float ncx = w->rayf[3][rl], ncy = w->rayf[4][rl], ncz = w->rayf[5][rl];
+    const float tolf = __builtin_fabsf(w->tolf[rl]); /* NaN: then nothing is ever certain */
+    have = have && !(item_t > thrf); /* fallen behind the threshold since it was pushed */
+    const float bx[24] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w,
+                          q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w};
+    const uint32_t code[4] = {ch.x, ch.y, ch.z, ch.w};
+    bool pn[4], pl[4];
+    float f[4];
+    int cn = 0, cl = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const float t1x = __builtin_fmaf(bx[6 * c], iux, ncx), t2x = __builtin_fmaf(bx[6 * c + 3], iux, ncx);
+        const float t1y = __builtin_fmaf(bx[6 * c + 1], iuy, ncy), t2y = __builtin_fmaf(bx[6 * c + 4], iuy, ncy);
+        const float t1z = __builtin_fmaf(bx[6 * c + 2], iuz, ncz), t2z = __builtin_fmaf(bx[6 * c + 5], iuz, ncz);
+        const float tMax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
+        const float tMin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
+        const bool miss = (tMax - tMin < -tolf) | (tMax < -tolf);
+        const float tlo = tMin - tolf;
+        const bool go = have & (code[c] != RT_CHILD_EMPTY) & !miss & !(tlo > thrf); /* no short cuts: straight-line code */
+        pn[c] = go & !(code[c] >> 31);
+        pl[c] = go & (bool)(code[c] >> 31);
+        f[c] = lower_float(tlo);
+        cn += pn[c] ? 1 : 0;
+        cl += pl[c] ? 1 : 0;
+    }
+    const int in_both = wave_scan_add(cn | (cl << 16)); /* both prefix sums at once: each stays below 2^16 */
+    const int in_n = in_both & 0xFFFF, in_l = in_both >> 16;
+    const int tot_both = __builtin_amdgcn_readlane(in_both, 63);
+    const int tot_n = tot_both & 0xFFFF, tot_l = tot_both >> 16;
+    if (n_nodes + tot_n > sc.node_cap || n_leaves + tot_l > RT_LEAF_CAP) { /* cannot happen for a validated scene; never write past the stacks */
+        if (lane == 0) atomicOr(sc.overflow, 1);
+    } else {
+        int jn = n_nodes + in_n - cn, jl = n_leaves + in_l - cl;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (pn[c]) { w->node[jn] = make_uint2(code[c] | ((uint32_t)rl << RT_NODE_BITS), __float_as_uint(f[c])); jn++; }
+            if (pl[c]) {
+                w->leaf[jl] = make_uint2(code[c] & 0x0FFFFFFFu, (((code[c] >> 28) & 7u) + 1u) | ((uint32_t)rl << RT_NODE_BITS));
+                w->leaf_t[jl] = f[c];
+                jl++;
+            }
+        }
+        n_nodes = uni(n_nodes + tot_n);
+        n_leaves = uni(n_leaves + tot_l);
+    }
+}
+
 /* Scene::intersect, raytracer.cpp:930-951, for up to two rays per lane (slots lane and 64 + lane). Called by all
  * 64 lanes together; active rays get their closest hit. */
 template <bool CNT>
@@ -566,14 +620,24 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScen
          * next mesh is fed whenever fewer than RT_FEED_BELOW node items are pending, so the traversals of
          * the meshes share their steps, and a root is already tested against the distance of the hits
          * found so far. */
-        if (own && mi == 0) { /* the filter tree has no root box: every active ray starts at record 0 */
+        if (own && mi == 0) {
+            /* The filter tree has no root box: every active ray starts at record 0, whose children are tested here
+             * right away (the record is read with wave-uniform addresses). The second rays go the same way if their
+             * pushes are sure to fit; otherwise they enter as items for record 0 and take an ordinary step. */
             mi = 1;
-            const unsigned long long ba = __ballot(qa.active), bb = __ballot(qb.active);
-            const int ca = __popcll(ba);
-            const uint32_t ninf = __float_as_uint(-__builtin_huge_valf());
-            if (qa.active) w->node[rank_in(ba)] = make_uint2((uint32_t)lane << RT_NODE_BITS, ninf);
-            if (qb.active) w->node[ca + rank_in(bb)] = make_uint2((uint32_t)(RT_WAVE + lane) << RT_NODE_BITS, ninf);
-            n_nodes = ca + __popcll(bb);
+            const float4 *rp = reinterpret_cast<const float4 *>(sc.own_rec4);
+            const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3], q4 = rp[4], q5 = rp[5];
+            const uint4 ch = *reinterpret_cast<const uint4 *>(rp + 6);
+            const float ninf = -__builtin_huge_valf();
+            wide_children(sc, w, lane, qa.active, lane, ninf, q0, q1, q2, q3, q4, q5, ch, n_nodes, n_leaves);
+            const unsigned long long bb = __ballot(qb.active);
+            const int nb = __popcll(bb);
+            if (n_nodes + 4 * nb <= RT_NODE_SOFT && n_leaves + 4 * nb <= RT_LEAF_CAP) {
+                wide_children(sc, w, lane, qb.active, RT_WAVE + lane, ninf, q0, q1, q2, q3, q4, q5, ch, n_nodes, n_leaves);
+            } else {
+                if (qb.active) w->node[n_nodes + rank_in(bb)] = make_uint2((uint32_t)(RT_WAVE + lane) << RT_NODE_BITS, __float_as_uint(ninf));
+                n_nodes += nb;
+            }
             wave_sync();
         }
         if (mi < n_feed && n_nodes < RT_FEED_BELOW && n_leaves <= RT_WAVE) {
@@ -728,54 +792,7 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScen
                 const float4 *rp = reinterpret_cast<const float4 *>(sc.own_rec4 + rec);
                 const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3], q4 = rp[4], q5 = rp[5];
                 const uint4 ch = *reinterpret_cast<const uint4 *>(rp + 6);
-                /* the filter only ever needs "certainly missed" (box_fast_f's miss); its boxes are rounded outwards */
-                const float thrf = w->thrf[rl];
-                const float iux = w->rayf[0][rl], iuy = w->rayf[1][rl], iuz = w->rayf[2][rl];
-                const float ncx = w->rayf[3][rl], ncy = w->rayf[4][rl], ncz = w->rayf[5][rl];
-                const float tolf = __builtin_fabsf(w->tolf[rl]); /* NaN: then nothing is ever certain */
-                have = have && !(__uint_as_float(it.y) > thrf); /* fallen behind the threshold since it was pushed */
-                const float bx[24] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w,
-                                      q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w};
-                const uint32_t code[4] = {ch.x, ch.y, ch.z, ch.w};
-                bool pn[4], pl[4];
-                float f[4];
-                int cn = 0, cl = 0;
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const float t1x = __builtin_fmaf(bx[6 * c], iux, ncx), t2x = __builtin_fmaf(bx[6 * c + 3], iux, ncx);
-                    const float t1y = __builtin_fmaf(bx[6 * c + 1], iuy, ncy), t2y = __builtin_fmaf(bx[6 * c + 4], iuy, ncy);
-                    const float t1z = __builtin_fmaf(bx[6 * c + 2], iuz, ncz), t2z = __builtin_fmaf(bx[6 * c + 5], iuz, ncz);
-                    const float tMax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
-                    const float tMin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
-                    const bool miss = (tMax - tMin < -tolf) | (tMax < -tolf);
-                    const float tlo = tMin - tolf;
-                    const bool go = have & (code[c] != RT_CHILD_EMPTY) & !miss & !(tlo > thrf); /* no short cuts: straight-line code */
-                    pn[c] = go & !(code[c] >> 31);
-                    pl[c] = go & (bool)(code[c] >> 31);
-                    f[c] = __builtin_fmaf(-__builtin_fabsf(tlo), 0x1p-22f, tlo) - 0x1p-125f;
-                    cn += pn[c] ? 1 : 0;
-                    cl += pl[c] ? 1 : 0;
-                }
-                const int in_both = wave_scan_add(cn | (cl << 16)); /* both prefix sums at once: each stays below 2^16 */
-                const int in_n = in_both & 0xFFFF, in_l = in_both >> 16;
-                const int tot_both = __builtin_amdgcn_readlane(in_both, 63);
-                const int tot_n = tot_both & 0xFFFF, tot_l = tot_both >> 16;
-                if (n_nodes + tot_n > sc.node_cap || n_leaves + tot_l > RT_LEAF_CAP) { /* cannot happen for a validated scene; never write past the stacks */
-                    if (lane == 0) atomicOr(sc.overflow, 1);
-                } else {
-                    int jn = n_nodes + in_n - cn, jl = n_leaves + in_l - cl;
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        if (pn[c]) { w->node[jn] = make_uint2(code[c] | ((uint32_t)rl << RT_NODE_BITS), __float_as_uint(f[c])); jn++; }
-                        if (pl[c]) {
-                            w->leaf[jl] = make_uint2(code[c] & 0x0FFFFFFFu, (((code[c] >> 28) & 7u) + 1u) | ((uint32_t)rl << RT_NODE_BITS));
-                            w->leaf_t[jl] = f[c];
-                            jl++;
-                        }
-                    }
-                    n_nodes = uni(n_nodes + tot_n);
-                    n_leaves = uni(n_leaves + tot_l);
-                }
+                wide_children(sc, w, lane, have, rl, __uint_as_float(it.y), q0, q1, q2, q3, q4, q5, ch, n_nodes, n_leaves);
                 wave_sync();
                 if (CNT) { uint64_t t = RT_STAMP(); cnt.cyc_node += t - st0; st0 = t; cnt.node_steps++; cnt.node_lanes += (uint64_t)k; }
             } else {
