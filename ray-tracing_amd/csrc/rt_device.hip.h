@@ -207,7 +207,7 @@ __device__ __noinline__ bool box_hit_exact(const double *b, double cx, double cy
  * covers that twice over (the test compares tMax - tMin, which carries two such errors). Rays for which
  * the bound cannot be trusted (a zero, huge, tiny or non-finite direction component or origin, or a
  * scene whose boxes do not fit a float) get tol = NaN: no comparison with it holds and every one of
- * their boxes goes to the exact test. This double-precision form confirms the filter tree's winners (ray_end);
+ * their boxes goes to the exact test. This double-precision form confirms the filter tree's winners (rays_end);
  * the traversal itself uses the single-precision form below. */
 struct RayK {
     V3 iu, nc;
@@ -469,37 +469,72 @@ __device__ __forceinline__ void ray_begin(const DScene &sc, WaveLDS *w, const rt
     w->thrf[slot] = (prune && t0 < 1E9) ? upper_float(t0 * RT_PRUNE_SLACK) : __builtin_huge_valf();
 }
 
-/* The mesh hit of one ray, and Scene::intersect's choice between it and the sphere hit. After a traversal of the
- * filter tree (own) the winner is first checked against the reference's own tree: the reference reaches a
- * triangle iff the box test passes for its leaf and every box above it (raytracer.cpp:644-665), those boxes
- * contain the leaf's box coordinate by coordinate, and the slab test is monotone in the box (each of its
- * operations is), so "the leaf's box is certainly hit" settles all of them. Anything less - a grazed or flat
- * leaf box, a hit without a triangle - returns true: the ray has to be traced again on the reference's tree. */
-__device__ __forceinline__ bool ray_end(const DScene &sc, WaveLDS *w, int slot, const RayQ &q, bool own, HitRec &h) {
-    if (!q.active) return false;
-    const double tm = __longlong_as_double((long long)w->best_t[slot]);
-    const int32_t pos = w->best_pos[slot];
-    if (pos != INT32_MAX) {
-        const bool phantom = pos >= RT_PHANTOM_BASE; /* the mesh reported a hit at t = 1E9 without a triangle */
+/* The mesh hits of a lane's two rays, and Scene::intersect's choice between each and the sphere hit. After a
+ * traversal of the filter tree (own) the winner is first checked against the reference's own tree: the reference
+ * reaches a triangle iff the box test passes for its leaf and every box above it (raytracer.cpp:644-665), those boxes
+ * contain the leaf's box coordinate by coordinate, and the slab test is monotone in the box (each of its operations
+ * is), so "the leaf's box is certainly hit" settles all of them. Anything less - a grazed or flat leaf box, a hit
+ * without a triangle - sets the ray's `doubt`: it has to be traced again on the reference's tree.
+ * Both rays go through the same straight-line code so that their loads (triangle, leaf index; then leaf box and
+ * object id) are in flight together; a ray without a triangle reads entry 0 and is masked. */
+__device__ __forceinline__ void rays_end(const DScene &sc, WaveLDS *w, int lane, const RayQ &qa, const RayQ &qb, bool own, HitRec &ha, HitRec &hb,
+                                         bool &doubt_a, bool &doubt_b) {
+    const RayQ *const q[2] = {&qa, &qb};
+    HitRec *const h[2] = {&ha, &hb};
+    bool doubt[2] = {false, false};
+    int32_t pos[2], mesh[2], leaf[2] = {0, 0}, oid[2];
+    double tm[2];
+    bool live[2], ph[2], tr[2];
+    Tri3 T[2];
+    float lb[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int slot = lane + r * RT_WAVE;
+        pos[r] = w->best_pos[slot];
+        tm[r] = __longlong_as_double((long long)w->best_t[slot]);
+        live[r] = q[r]->active && pos[r] != INT32_MAX;
+        ph[r] = live[r] && pos[r] >= RT_PHANTOM_BASE; /* the mesh reported a hit at t = 1E9 without a triangle */
+        tr[r] = live[r] && !ph[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const uint32_t p0 = tr[r] ? (uint32_t)pos[r] : 0u;
+        T[r] = tri_load(sc.tris, p0);
+        mesh[r] = sc.tris[p0].mesh;
+        if (own) leaf[r] = sc.tri_leaf[p0];
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        if (!tr[r]) mesh[r] = ph[r] ? pos[r] - RT_PHANTOM_BASE : 0;
+        oid[r] = sc.meshes[mesh[r]].object_id;
         if (own) {
-            if (phantom) return true;
-            const float *lb = sc.leaf_box32 + (size_t)sc.tri_leaf[pos] * 6;
-            const RayK k = ray_constants(sc, q.C, q.u); /* the double-precision form: as few rays as possible should go round again */
-            bool hit, unsure;
-            double tlo;
-            box_fast(Box6{(double)lb[0], (double)lb[1], (double)lb[2], (double)lb[3], (double)lb[4], (double)lb[5]}, k, hit, unsure, tlo);
-            if (!hit) return true;
-        }
-        const int32_t mi2 = phantom ? pos - RT_PHANTOM_BASE : sc.tris[pos].mesh;
-        const double tmm = phantom ? 1E9 : tm;
-        const int32_t oid = sc.meshes[mi2].object_id;
-        if (tmm < h.t || (tmm == h.t && oid < h.obj)) {
-            h.t = tmm; h.obj = oid; h.prim = phantom ? -1 : pos; h.mesh = mi2;
-            double lt;
-            if (!phantom) (void)tri_test(sc, (uint32_t)pos, q.C, q.u, h.beta, h.gamma, lt); /* alpha, beta, gamma of the winner (:683-685) */
+            const float *b = sc.leaf_box32 + (size_t)leaf[r] * 6;
+            for (int a = 0; a < 6; a++) lb[r][a] = b[a];
         }
     }
-    return false;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        if (own) {
+            if (ph[r]) doubt[r] = true;
+            if (tr[r]) {
+                const RayK k = ray_constants(sc, q[r]->C, q[r]->u); /* the double-precision form: as few rays as possible should go round again */
+                bool hit, unsure;
+                double tlo;
+                box_fast(Box6{(double)lb[r][0], (double)lb[r][1], (double)lb[r][2], (double)lb[r][3], (double)lb[r][4], (double)lb[r][5]}, k, hit, unsure, tlo);
+                if (!hit) doubt[r] = true;
+            }
+        }
+        if (live[r] && !doubt[r]) {
+            const double tmm = ph[r] ? 1E9 : tm[r];
+            if (tmm < h[r]->t || (tmm == h[r]->t && oid[r] < h[r]->obj)) {
+                h[r]->t = tmm; h[r]->obj = oid[r]; h[r]->prim = ph[r] ? -1 : pos[r]; h[r]->mesh = mesh[r];
+                double lt;
+                if (!ph[r]) (void)tri_eval(T[r], q[r]->C, q[r]->u, h[r]->beta, h[r]->gamma, lt); /* alpha, beta, gamma of the winner (:683-685) */
+            }
+        }
+    }
+    doubt_a = doubt[0];
+    doubt_b = doubt[1];
 }
 
 /* the mesh root box of one ray (raytracer.cpp:644); k and thr are the ray's constants as read at the start of the feed */
@@ -875,8 +910,8 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScen
             }
         }
     }
-    const bool da = ray_end(cold, w, lane, qa, own, ha);
-    const bool db = ray_end(cold, w, RT_WAVE + lane, qb, own, hb);
+    bool da, db;
+    rays_end(cold, w, lane, qa, qb, own, ha, hb, da, db);
     wave_sync();
     if (!own || __ballot(da || db) == 0ull) break;
     if (CNT) { cnt.dbg[6] += (uint64_t)(__popcll(__ballot(da)) + __popcll(__ballot(db))); cnt.dbg[7]++; }
@@ -1036,6 +1071,8 @@ __device__ __forceinline__ void path_advance(const DScene &sc, const rt_sphere *
     const uint32_t fl = p.flags;
     const double epsilon = p.epsilon;
     bool done = false;
+    uint64_t ts = 0;
+    if (CNT && RT_STAMP_STEPS) ts = RT_STAMP();
     if (q.shadow) {
         /* raytracer.cpp:1073-1083 (or :1048-1055 for the point light): occluded iff hit before the light */
         if (!(inter_s && hs.t < q.sh_limit)) q.Lsum = add(q.Lsum, cmul(q.T, q.nee));
@@ -1061,6 +1098,7 @@ __device__ __forceinline__ void path_advance(const DScene &sc, const rt_sphere *
     } else {
         Surf s;
         hit_surface(sc, sph, q.rC, q.ru, h, s);
+        if (CNT && RT_STAMP_STEPS) { pin3(s.P); pin3(s.N); pin3(s.albedo); const uint64_t t = RT_STAMP(); cnt.dbg[0] += t - ts; ts = t; }
         const V3 P = s.P, N = s.N, ru = q.ru;
         if (s.flags & RT_MAT_MIRROR) { /* :974-979 */
             if (CNT) cnt.specular++;
@@ -1144,6 +1182,7 @@ __device__ __forceinline__ void path_advance(const DScene &sc, const rt_sphere *
             q.shadow = true;
         }
     }
+    if (CNT && RT_STAMP_STEPS) { pin3(q.ru); pin3(q.shU); pin3(q.nee); cnt.dbg[1] += RT_STAMP() - ts; }
     if (done) {
         q.acc = add(q.acc, q.Lsum);
         q.k++;

@@ -6,7 +6,7 @@
  * a second tree built here over ALL triangles of the scene - binned surface-area cuts, leaves of at most
  * four triangles, triangles copied into this tree's own order - and uses it only to find candidate hits:
  * a ray is kept out of a box just when it certainly misses it. Whether the reference would have reached
- * the winning triangle is then checked on the reference's own leaf box (rt_device.hip.h: ray_end).
+ * the winning triangle is then checked on the reference's own leaf box (rt_device.hip.h: rays_end).
  */
 #pragma once
 #include <math.h>

@@ -20,5 +20,5 @@ out.update(node_fill=d["node_lanes"] / max(1, d["node_steps"]) / 64, leaf_fill=d
            cyc_per_leaf_step=d["cyc_leaf"] / max(1, d["leaf_steps"]), node_steps_per_query=d["node_steps"] / d["queries"],
            leaf_steps_per_query=d["leaf_steps"] / d["queries"], cyc_per_query_total=tot / d["queries"], ms=r.last_render_ms()[0], counters=c,
            dbg_per_node_step=[round(x / max(1, d["node_steps"]), 1) for x in dbg[:4]], dbg_per_leaf_step=[round(x / max(1, d["leaf_steps"]), 1) for x in dbg[4:]])
-out['second_pass_rays'] = dbg[6]; out['second_passes'] = dbg[7]; out['queries'] = d['queries']
+out['dbg_raw'] = dbg; out['cyc_total'] = tot; out['second_pass_rays'] = dbg[6]; out['second_passes'] = dbg[7]; out['queries'] = d['queries']
 print(json.dumps(out, indent=1))
