@@ -6,7 +6,7 @@ cp $L /tmp/base.so
 mkdir -p gpurun_out/ab
 for v in base "$@"; do
   if [ $v = base ]; then cp /tmp/base.so $L; else cp ray-tracing_amd/csrc/variants/$v.so $L; fi
-  timeout -k 10 200 python -u bench.py --no-cpu-baseline --steps 3 > gpurun_out/ab/$v.log 2>&1 || { echo "$v FAILED"; tail -3 gpurun_out/ab/$v.log; exit 1; }
+  timeout -k 10 200 python -u bench.py --no-cpu-baseline --steps 3 --spp-step ${SPP:-16} > gpurun_out/ab/$v.log 2>&1 || { echo "$v FAILED"; tail -3 gpurun_out/ab/$v.log; exit 1; }
   python - $v <<'PY'
 import json,sys
 l=[x for x in open("gpurun_out/ab/%s.log"%sys.argv[1]) if x.startswith("{")][-1]; d=json.loads(l)
