@@ -185,6 +185,8 @@ def main():
         sz = (ctypes.c_uint64 * 4)()
         rta.lib.rt_debug_scene_sizes(r._h, sz)  # device bytes with every derived array; record counts
         sizes = [int(x) for x in sz]
+        occ_b, occ_l = ctypes.c_int(), ctypes.c_int()
+        rta.lib.rt_debug_occupancy(r._h, ctypes.byref(occ_b), ctypes.byref(occ_l))  # resident waves per CU with this scene's LDS use
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import bindings as ob
@@ -211,7 +213,8 @@ def main():
                                                                                       1000.0 * W * H / (value * 1e6)),
                           "spp_per_step": args.spp_step, "parallelism": "spp-sharded x%d + RCCL reduce(sum) of the f64 accumulator" % world,
                           "scene_bytes_hbm": info["bytes"], "scene_bytes_device": sizes[0], "traversal_records": sizes[1],
-                          "filter_tree_records": sizes[2], "setup_s": round(setup_s, 2)},
+                          "filter_tree_records": sizes[2], "waves_per_cu": min(occ_b.value, 8), "lds_bytes_per_wave": occ_l.value,
+                          "setup_s": round(setup_s, 2)},
                "rays_per_s": round(value * 1e6 * c["rays"] / c["paths"], 1),
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out))

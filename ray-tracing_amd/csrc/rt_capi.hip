@@ -546,13 +546,22 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
         d.lightR = light->R;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream)); /* host arrays may be released after return */
-    d.node_cap = RT_NODE_SOFT + (own_depth > max_depth + ext_depth ? own_depth : max_depth + ext_depth) + 2;
+    const int depth_need = (own_depth > max_depth + ext_depth ? own_depth : max_depth + ext_depth) + 2;
+    const size_t lds_fixed = sizeof(WaveLDS) + 16 + ((s->n_spheres <= RT_LDS_SPHERES_MAX) ? (size_t)s->n_spheres * sizeof(rt_sphere) : 0);
+    {
+        /* One more resident wave per CU is worth more than a tall stack (measured: +11 % for the eighth wave, -2 % for
+         * 320 instead of 384 entries): the stack is shortened, within limits, to keep the wave's LDS inside an eighth
+         * of the CU's 160 KiB. */
+        const long fit = ((long)(160 * 1024 / 8) - (long)lds_fixed) / 8 - depth_need;
+        d.node_soft = fit >= RT_NODE_SOFT ? RT_NODE_SOFT : (fit >= RT_NODE_SOFT_MIN ? (int)fit : RT_NODE_SOFT);
+    }
+    d.node_cap = d.node_soft + depth_need;
     d.overflow = c->d_overflow;
     for (int k = 0; k < 3; k++) d.bmax[k] = bmax[k];
     d.n_tris_total = (uint32_t)s->n_tris;
     d.n_ref_nodes = (uint32_t)s->n_nodes;
     c->sc = d;
-    c->lds_bytes = sizeof(WaveLDS) + (size_t)d.node_cap * 8 + 16 + ((s->n_spheres <= RT_LDS_SPHERES_MAX) ? (size_t)s->n_spheres * sizeof(rt_sphere) : 0);
+    c->lds_bytes = lds_fixed + (size_t)d.node_cap * 8;
     if (c->lds_bytes > 64 * 1024) return fail(c, RT_E_INVALID, "rt_upload_scene: per-wave LDS of %zu bytes exceeds 64 KiB", c->lds_bytes);
     /* persistent waves of the render kernel that stay resident on one CU with this scene's LDS use */
     {

@@ -34,12 +34,14 @@ namespace rtd {
 
 #define RT_WAVE 64
 #define RT_LDS_SPHERES_MAX 64     /* sphere lists up to this size are staged in LDS */
-#ifndef RT_FEED_BELOW
-#define RT_FEED_BELOW 256         /* mesh roots are fed to the pool while fewer node items than this are pending (measured: the more the better) */
-#endif
 #ifndef RT_NODE_SOFT
-#define RT_NODE_SOFT 384
-#endif          /* node-item stack height up to which 64 items are popped per step */
+#define RT_NODE_SOFT 384          /* node-item stack height up to which 64 items are popped per step: the largest value the host
+                                     gives DScene::node_soft; it takes a smaller one (down to RT_NODE_SOFT_MIN) if that lets one
+                                     more wave stay resident per CU */
+#endif
+#define RT_NODE_SOFT_MIN 288
+#define RT_FEED_MARGIN (2 * RT_WAVE) /* mesh roots are fed to the pool while fewer than node_soft - RT_FEED_MARGIN node items are
+                                        pending: a fed mesh adds up to 128 (measured: the more are fed the better) */
 #ifndef RT_LEAF_CAP
 #define RT_LEAF_CAP 320           /* leaf-item stack entries */
 #endif
@@ -54,7 +56,7 @@ namespace rtd {
 #ifndef RT_EXT_LEAF
 #define RT_EXT_LEAF 4             /* reference leaves with more triangles than this get extension records down to this size */
 #endif
-static_assert(RT_FEED_BELOW + 2 * RT_WAVE <= RT_NODE_SOFT, "a fed mesh adds up to 128 node items on top of RT_FEED_BELOW - 1");
+static_assert(RT_NODE_SOFT_MIN > RT_FEED_MARGIN + RT_WAVE && RT_NODE_SOFT_MIN <= RT_NODE_SOFT, "the feed needs room for a mesh above a useful stack height");
 static_assert(RT_LEAF_CAP >= 5 * RT_WAVE, "a node step adds up to 256 leaf items (filter tree: four children) and runs only when 256 slots are free; a fed mesh adds up to 128 on top of 64");
 #define RT_PHANTOM_BASE (1 << 30)  /* best_pos values from here on: "mesh (value - base) reports a hit without a triangle" */
 
@@ -111,8 +113,8 @@ struct DScene {
     const uint8_t *texels;
     const double *lut;
     int32_t n_spheres, n_meshes;
-    int32_t node_cap; /* node-item stack entries: RT_NODE_SOFT + max_depth + 2 */
-    int32_t pad;
+    int32_t node_cap;  /* node-item stack entries: node_soft + the deepest tree's needs + 2 */
+    int32_t node_soft; /* stack height up to which 64 items are popped per step (RT_NODE_SOFT_MIN .. RT_NODE_SOFT) */
     double bmax[3];   /* largest |coordinate| of any box of the scene, per axis (infinity if one is not finite) */
     uint32_t n_tris_total, n_nodes_total; /* array lengths: every index taken from the pool is checked against them */
     uint32_t n_ref_nodes;                 /* records below this index are the reference's; the rest are extension records */
@@ -645,6 +647,7 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScen
     const rt_tri *const tri_base = own ? sc.own_tris : sc.tris;
     const uint32_t n_recs = own ? sc.n_own_nodes : sc.n_nodes_total;
     const uint32_t n_tri_lim = own ? sc.n_own_tris : sc.n_tris_total;
+    const int node_soft = sc.node_soft, feed_below = sc.node_soft - RT_FEED_MARGIN;
     const int n_feed = own ? 1 : sc.n_meshes;
 
     int n_nodes = 0, n_leaves = 0; /* wave-uniform stack heights */
@@ -652,7 +655,7 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScen
     unsigned steps = 0;
     for (;;) {
         /* Root boxes (raytracer.cpp:644): every lane for its own rays; roots that pass enter the pool. The
-         * next mesh is fed whenever fewer than RT_FEED_BELOW node items are pending, so the traversals of
+         * next mesh is fed whenever fewer than node_soft - RT_FEED_MARGIN node items are pending, so the traversals of
          * the meshes share their steps, and a root is already tested against the distance of the hits
          * found so far. */
         if (own && mi == 0) {
@@ -667,7 +670,7 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScen
             wide_children(sc, w, lane, qa.active, lane, ninf, q0, q1, q2, q3, q4, q5, ch, n_nodes, n_leaves);
             const unsigned long long bb = __ballot(qb.active);
             const int nb = __popcll(bb);
-            if (n_nodes + 4 * nb <= RT_NODE_SOFT && n_leaves + 4 * nb <= RT_LEAF_CAP) {
+            if (n_nodes + 4 * nb <= node_soft && n_leaves + 4 * nb <= RT_LEAF_CAP) {
                 wide_children(sc, w, lane, qb.active, RT_WAVE + lane, ninf, q0, q1, q2, q3, q4, q5, ch, n_nodes, n_leaves);
             } else {
                 if (qb.active) w->node[n_nodes + rank_in(bb)] = make_uint2((uint32_t)(RT_WAVE + lane) << RT_NODE_BITS, __float_as_uint(ninf));
@@ -675,7 +678,7 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScen
             }
             wave_sync();
         }
-        if (mi < n_feed && n_nodes < RT_FEED_BELOW && n_leaves <= RT_WAVE) {
+        if (mi < n_feed && n_nodes < feed_below && n_leaves <= RT_WAVE) {
             const RayKf ka = ray_k_from_lds(w, lane), kb = ray_k_from_lds(w, RT_WAVE + lane);
             const float thr_a = w->thrf[lane], thr_b = w->thrf[RT_WAVE + lane]; /* as of now: thresholds only fall */
             do {
@@ -704,7 +707,7 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScen
                     }
                     n_leaves = uni(n_leaves + ca + __popcll(bb));
                 }
-            } while (mi < n_feed && n_nodes < RT_FEED_BELOW && n_leaves <= RT_WAVE);
+            } while (mi < n_feed && n_nodes < feed_below && n_leaves <= RT_WAVE);
             wave_sync();
             if (CNT) { uint64_t t = RT_STAMP(); cnt.cyc_roots += t - st0; st0 = t; }
         }
@@ -808,10 +811,10 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScen
             } else if (own) {
                 /* Filter tree: up to 64 four-child records per step, one per lane. A child is pushed unless the
                  * ray certainly misses its box or the box starts beyond the ray's threshold. A step pops k
-                 * records and pushes at most 4 k, so k is held to a third of the room below RT_NODE_SOFT; above
+                 * records and pushes at most 4 k, so k is held to a third of the room below node_soft; above
                  * it one record per step (depth-first: three more entries per level at most). */
                 int k = n_nodes < RT_WAVE ? n_nodes : RT_WAVE;
-                const int room = (RT_NODE_SOFT - n_nodes) / 3;
+                const int room = (node_soft - n_nodes) / 3;
                 if (k > room) k = room > 1 ? room : 1;
                 bool have = lane < k;
                 const uint2 it = w->node[have ? n_nodes - 1 - lane : 0];
@@ -833,12 +836,12 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScen
             } else {
                 /* Up to 64 BVH records per step, one per lane: both child boxes are tested (raytracer.cpp:656-665)
                  * and the children that are hit are pushed. 64 records are popped while the stack is below
-                 * RT_NODE_SOFT (a step can add one entry per record popped); above it one record per step,
+                 * node_soft (a step can add one entry per record popped); above it one record per step,
                  * a plain depth-first descent that needs at most max_depth + 1 entries more.
                  * Branch-free up to the box decisions, so that all loads of the step are in flight before the
                  * first is waited for: a lane without a record reads slot 0 / record 0 and is masked out. */
                 int k = n_nodes < RT_WAVE ? n_nodes : RT_WAVE;
-                const int room = RT_NODE_SOFT - n_nodes;
+                const int room = node_soft - n_nodes;
                 if (k > room) k = room > 1 ? room : 1;
                 bool have = lane < k;
                 const uint2 it = w->node[have ? n_nodes - 1 - lane : 0];
