@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP64_VECTOR_TFLOPS = 78.6   # MI355X vector FP64 = half the 157.3 TFLOP/s FP32 vector peak
 PEAK_HBM_GBS = 8000.0
-PROFILE_PREFIX = "r1_v8_filter_tree_"  # rocprofv3 summaries of this round's kernel under profiles/
+PROFILE_PREFIX = "r1_v9_eight_waves_"  # rocprofv3 summaries of this round's kernel under profiles/
 
 
 def algorithmic_flops(c, n_spheres):
@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp-step", type=int, default=16, help="samples per pixel per rank per step")
+    ap.add_argument("--spp-step", type=int, default=64, help="samples per pixel per rank per step (one kernel launch up to 64)")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=12, help="samples per pixel of the CPU baseline's bounded sample (12 spp = about 15 s on 16 cores)")
@@ -176,9 +176,12 @@ def main():
             pm = json.load(open(os.path.join(ROOT, "profiles", PROFILE_PREFIX + "mem2.json")))
             kk = [k for k in pm if "rt_render_kernel<false>" in k][0]
             roofline["traffic"] = round(pm[kk]["FETCH_SIZE"] * 1024.0 * 2.0 / pm[kk]["dispatches"], 1)
-            roofline["traffic_note"] = ("bytes per launch of 1024x1024x16 paths from profiles/%smem2.json (rocprofv3 --pmc FETCH_SIZE of "
-                                        "`bench.py --steps 2 --warmup 1 --spp-step 16`), x2 gfx950 correction; algorithmic bytes per launch = %.4g"
-                                        % (PROFILE_PREFIX, bytes_per_path * paths_per_launch))
+            roofline["traffic_note"] = ("bytes per launch of 1024x1024x64 paths from profiles/%smem2.json (rocprofv3 --pmc FETCH_SIZE of "
+                                        "`bench.py --steps 2 --warmup 1 --no-cpu-baseline`, 64 spp per launch), x2 gfx950 correction; "
+                                        "algorithmic bytes per launch = %.4g" % (PROFILE_PREFIX, bytes_per_path * paths_per_launch))
+            if args.spp_step != 64 or W != 1024:
+                roofline["traffic"] = None  # the committed counter pass is of the default launch size only
+                roofline["traffic_note"] = "no counter pass for this launch size"
         except (OSError, KeyError, IndexError, ValueError, ZeroDivisionError):
             pass
         import ctypes

@@ -56,7 +56,10 @@ static inline void box_to_float(const Bounds &b, float *box) { /* rounded outwar
 }
 
 static const int kBins = 16;
-static const int kLeaf = 4;
+#ifndef RT_OWN_LEAF
+#define RT_OWN_LEAF 4
+#endif
+static const int kLeaf = RT_OWN_LEAF; /* at most 8: the leaf count has three bits in a child code */
 static const int kSahDepth = 40; /* below this depth ranges are halved by count, which bounds the depth */
 
 inline Built build(const rt_tri *tris, int64_t n) {
