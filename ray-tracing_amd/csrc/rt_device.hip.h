@@ -1035,8 +1035,10 @@ __device__ __forceinline__ void path_fresh(const RenderArgs &ra, Path &q, int i,
     if (p.flags & RT_F_NO_JITTER) { /* Ray r(C, u), raytracer.cpp:1482 */
         V3 d = mk(j - p.W / 2 + 0.5, i - p.H / 2 + 0.5, cam.zdist);
         d = unit(d);
-        q.ru = add(add(smul(d.x, right), smul(d.y, up)), smul(d.z, view));
-        q.rC = camC;
+        const V3 dir = add(add(smul(d.x, right), smul(d.y, up)), smul(d.z, view));
+        q.rC = camC; /* both branches assign rC, then ru: stores in a different order get merged into stores through a
+                        selected address, and the path state then stays in scratch memory instead of registers */
+        q.ru = dir;
     } else { /* raytracer.cpp:1467-1483 */
         double u1 = rng_uniform(q.key, 0), u2 = rng_uniform(q.key, 1);
         double s1, c1, s3, c3;
