@@ -325,6 +325,8 @@ struct HitRec {
     int32_t obj;  /* objectId, INT32_MAX while nothing is hit */
     int32_t prim; /* sphere index, or global triangle position */
     int32_t mesh; /* mesh index or -1 for a sphere */
+    int32_t group; /* the triangle's texture group, for a path segment's mesh hit: read while the hit is settled, which also
+                      brings the triangle's attribute record into the cache before the surface is evaluated */
     double beta, gamma;
 };
 
@@ -425,6 +427,7 @@ __device__ __forceinline__ void ray_begin(const DScene &sc, WaveLDS *w, const rt
     h.obj = INT32_MAX;
     h.prim = -1;
     h.mesh = -1;
+    h.group = 0;
     h.beta = h.gamma = 0;
     if (!q.active) return;
     const V3 C = q.C, u = q.u;
@@ -484,7 +487,7 @@ __device__ __forceinline__ void rays_end(const DScene &sc, WaveLDS *w, int lane,
     const RayQ *const q[2] = {&qa, &qb};
     HitRec *const h[2] = {&ha, &hb};
     bool doubt[2] = {false, false};
-    int32_t pos[2], mesh[2], leaf[2] = {0, 0}, oid[2];
+    int32_t pos[2], mesh[2], leaf[2] = {0, 0}, oid[2], group = 0;
     double tm[2];
     bool live[2], ph[2], tr[2];
     Tri3 T[2];
@@ -503,6 +506,7 @@ __device__ __forceinline__ void rays_end(const DScene &sc, WaveLDS *w, int lane,
         const uint32_t p0 = tr[r] ? (uint32_t)pos[r] : 0u;
         T[r] = tri_load(sc.tris, p0);
         mesh[r] = sc.tris[p0].mesh;
+        if (r == 0) group = sc.attrs[p0].group; /* only a path segment's hit is shaded */
         if (own) leaf[r] = sc.tri_leaf[p0];
     }
 #pragma unroll
@@ -530,6 +534,7 @@ __device__ __forceinline__ void rays_end(const DScene &sc, WaveLDS *w, int lane,
             const double tmm = ph[r] ? 1E9 : tm[r];
             if (tmm < h[r]->t || (tmm == h[r]->t && oid[r] < h[r]->obj)) {
                 h[r]->t = tmm; h[r]->obj = oid[r]; h[r]->prim = ph[r] ? -1 : pos[r]; h[r]->mesh = mesh[r];
+                if (r == 0) h[r]->group = group;
                 double lt;
                 if (!ph[r]) (void)tri_eval(T[r], q[r]->C, q[r]->u, h[r]->beta, h[r]->gamma, lt); /* alpha, beta, gamma of the winner (:683-685) */
             }
@@ -957,7 +962,7 @@ __device__ __forceinline__ void hit_surface(const DScene &sc, const rt_sphere *s
         s.P = add(C, u); /* raytracer.cpp:696: C + u, not C + t u */
         s.flags = m.flags;
         if (m.n_tex > 0) {
-            const rt_texture tx = sc.tex[m.first_tex + at->group];
+            const rt_texture tx = sc.tex[m.first_tex + h.group];
             int H = tx.H, W = tx.W;
             double U = (alpha * at->uv[0][0] + beta * at->uv[1][0]) + gamma * at->uv[2][0];
             double V = (alpha * at->uv[0][1] + beta * at->uv[1][1]) + gamma * at->uv[2][1];
