@@ -585,7 +585,6 @@ __device__ __forceinline__ void wide_children(const DScene &sc, WaveLDS *w, int 
     const uint32_t code[4] = {ch.x, ch.y, ch.z, ch.w};
     bool pn[4], pl[4];
     float f[4];
-    int cn = 0, cl = 0;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         const float t1x = __builtin_fmaf(bx[6 * c], iux, ncx), t2x = __builtin_fmaf(bx[6 * c + 3], iux, ncx);
@@ -599,28 +598,32 @@ __device__ __forceinline__ void wide_children(const DScene &sc, WaveLDS *w, int 
         pn[c] = go & !(code[c] >> 31);
         pl[c] = go & (bool)(code[c] >> 31);
         f[c] = lower_float(tlo);
-        cn += pn[c] ? 1 : 0;
-        cl += pl[c] ? 1 : 0;
     }
-    const int in_both = wave_scan_add(cn | (cl << 16)); /* both prefix sums at once: each stays below 2^16 */
-    const int in_n = in_both & 0xFFFF, in_l = in_both >> 16;
-    const int tot_both = __builtin_amdgcn_readlane(in_both, 63);
-    const int tot_n = tot_both & 0xFFFF, tot_l = tot_both >> 16;
-    if (n_nodes + tot_n > sc.node_cap || n_leaves + tot_l > RT_LEAF_CAP) { /* cannot happen for a validated scene; never write past the stacks */
+    /* Places on the stacks: all first children, then all second children, ... - one ballot per child and kind, the
+     * lane's place among them by mbcnt, the offsets by scalar popcounts. No prefix sum over the lanes is needed. */
+    int jn[4], jl[4];
+    int tn = n_nodes, tl = n_leaves;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const unsigned long long mn = __ballot(pn[c]), ml = __ballot(pl[c]);
+        jn[c] = tn + rank_in(mn);
+        jl[c] = tl + rank_in(ml);
+        tn += __popcll(mn);
+        tl += __popcll(ml);
+    }
+    if (tn > sc.node_cap || tl > RT_LEAF_CAP) { /* cannot happen for a validated scene; never write past the stacks */
         if (lane == 0) atomicOr(sc.overflow, 1);
     } else {
-        int jn = n_nodes + in_n - cn, jl = n_leaves + in_l - cl;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            if (pn[c]) { w->node[jn] = make_uint2(code[c] | ((uint32_t)rl << RT_NODE_BITS), __float_as_uint(f[c])); jn++; }
+            if (pn[c]) w->node[jn[c]] = make_uint2(code[c] | ((uint32_t)rl << RT_NODE_BITS), __float_as_uint(f[c]));
             if (pl[c]) {
-                w->leaf[jl] = make_uint2(code[c] & 0x0FFFFFFFu, (((code[c] >> 28) & 7u) + 1u) | ((uint32_t)rl << RT_NODE_BITS));
-                w->leaf_t[jl] = f[c];
-                jl++;
+                w->leaf[jl[c]] = make_uint2(code[c] & 0x0FFFFFFFu, (((code[c] >> 28) & 7u) + 1u) | ((uint32_t)rl << RT_NODE_BITS));
+                w->leaf_t[jl[c]] = f[c];
             }
         }
-        n_nodes = uni(n_nodes + tot_n);
-        n_leaves = uni(n_leaves + tot_l);
+        n_nodes = tn;
+        n_leaves = tl;
     }
 }
 
@@ -827,6 +830,7 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScen
                 wave_sync();
                 const int rl = (int)(it.x >> RT_NODE_BITS);
                 uint32_t rec = it.x & RT_LOW_MASK;
+                if (CNT && RT_STAMP_STEPS) { asm volatile("" :: "v"(rec)); const uint64_t t = RT_STAMP(); cnt.dbg[0] += t - st0; st0 = t; } /* the item has arrived */
                 if (have && rec >= n_recs) { /* never fetch outside the arrays */
                     have = false;
                     atomicOr(sc.overflow, 2);
@@ -835,6 +839,10 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScen
                 const float4 *rp = reinterpret_cast<const float4 *>(sc.own_rec4 + rec);
                 const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3], q4 = rp[4], q5 = rp[5];
                 const uint4 ch = *reinterpret_cast<const uint4 *>(rp + 6);
+                if (CNT && RT_STAMP_STEPS) { /* the record has arrived */
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const uint64_t t = RT_STAMP(); cnt.dbg[1] += t - st0; st0 = t;
+                }
                 wide_children(sc, w, lane, have, rl, __uint_as_float(it.y), q0, q1, q2, q3, q4, q5, ch, n_nodes, n_leaves);
                 wave_sync();
                 if (CNT) { uint64_t t = RT_STAMP(); cnt.cyc_node += t - st0; st0 = t; cnt.node_steps++; cnt.node_lanes += (uint64_t)k; }
@@ -1081,8 +1089,6 @@ __device__ __forceinline__ void path_advance(const DScene &sc, const rt_sphere *
     const uint32_t fl = p.flags;
     const double epsilon = p.epsilon;
     bool done = false;
-    uint64_t ts = 0;
-    if (CNT && RT_STAMP_STEPS) ts = RT_STAMP();
     if (q.shadow) {
         /* raytracer.cpp:1073-1083 (or :1048-1055 for the point light): occluded iff hit before the light */
         if (!(inter_s && hs.t < q.sh_limit)) q.Lsum = add(q.Lsum, cmul(q.T, q.nee));
@@ -1108,7 +1114,6 @@ __device__ __forceinline__ void path_advance(const DScene &sc, const rt_sphere *
     } else {
         Surf s;
         hit_surface(sc, sph, q.rC, q.ru, h, s);
-        if (CNT && RT_STAMP_STEPS) { pin3(s.P); pin3(s.N); pin3(s.albedo); const uint64_t t = RT_STAMP(); cnt.dbg[0] += t - ts; ts = t; }
         const V3 P = s.P, N = s.N, ru = q.ru;
         if (s.flags & RT_MAT_MIRROR) { /* :974-979 */
             if (CNT) cnt.specular++;
@@ -1192,7 +1197,6 @@ __device__ __forceinline__ void path_advance(const DScene &sc, const rt_sphere *
             q.shadow = true;
         }
     }
-    if (CNT && RT_STAMP_STEPS) { pin3(q.ru); pin3(q.shU); pin3(q.nee); cnt.dbg[1] += RT_STAMP() - ts; }
     if (done) {
         q.acc = add(q.acc, q.Lsum);
         q.k++;
