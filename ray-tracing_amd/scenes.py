@@ -285,6 +285,50 @@ def stress(W=2048, n_tris=5_000_000, n_spheres=1000, seed=12345):
     return s, cam, 0
 
 
+def grid_mesh(n, f):
+    """(n x n)-quad grid mesh whose vertex (a, b), a, b = 0..n, lies at f(a, b): verts, normals, uvs, idx10"""
+    ii, jj = np.meshgrid(np.arange(n + 1), np.arange(n + 1), indexing="ij")
+    v = np.ascontiguousarray(f(ii.ravel().astype(np.float64), jj.ravel().astype(np.float64)), np.float64)
+    nrm = np.tile(np.array([[0.0, 1.0, 0.0]]), (len(v), 1))
+    uv = np.stack([ii.ravel() / n, jj.ravel() / n], 1).astype(np.float64)
+    q = (ii[:-1, :-1] * (n + 1) + jj[:-1, :-1]).ravel()
+    tris = np.concatenate([np.stack([q, q + 1, q + n + 2], 1), np.stack([q, q + n + 2, q + n + 1], 1)])
+    ix = np.zeros((len(tris), 10), np.int32)
+    ix[:, 0:3] = tris
+    ix[:, 3:6] = tris
+    ix[:, 6:9] = tris
+    return v, nrm, uv, ix
+
+
+def axis_aligned(W=64):
+    """Geometry in coordinate planes. A leaf whose box has no thickness along an axis is never entered by the
+    reference (tMax > tMin cannot hold, raytracer.cpp:184): object 2, a grid in the plane y = 2, is invisible as
+    a whole; object 3, a staircase of axis-aligned faces as truncation to integers produces them
+    (rotateAroundAxe, raytracer.cpp:831-834), is visible only where its leaves have a volume."""
+    s = Scene(I=6e9, L=(-10, 50, 40))
+    s.add(Sphere(s.L, 5, (1, 1, 1)))
+    s.add(Sphere((0, -1000, 0), 990, (1, 1, 1)))
+    flat = TriangleMesh((1, 0, 0))
+    flat.set_raw(*grid_mesh(24, lambda a, b: np.stack([a - 12, np.full_like(a, 2.0), b - 12], 1)))
+    flat.buildBVH()
+    s.add(flat)
+    stairs = TriangleMesh((0, 1, 0))
+    stairs.set_raw(*grid_mesh(40, lambda a, b: np.stack([np.trunc(a * 0.3) - 6, np.trunc((a + b) * 0.2) - 4, b * 0.5 - 10], 1)))
+    stairs.buildBVH()
+    s.add(stairs)
+    cam = make_camera((0, 30, 55), 60.0, -25.0, 0.0, W)
+    return s, cam, 0
+
+
+def rays_into_box(n, seed, org_lo, org_hi, tgt_lo, tgt_hi):
+    """n seeded rays from random origins in one box towards random targets in another: (n, 6) C, u"""
+    rng = np.random.default_rng(seed)
+    org = rng.uniform(org_lo, org_hi, (n, 3))
+    d = rng.uniform(tgt_lo, tgt_hi, (n, 3)) - org
+    d /= np.sqrt((d * d).sum(1))[:, None]
+    return np.ascontiguousarray(np.concatenate([org, d], 1))
+
+
 def export_objects(scene):
     """Plain-data view of a scene for checkers: list of dicts with final (post-transform) arrays.
     Call it on meshes BEFORE or AFTER buildBVH alike: indices are returned in face-fan order."""

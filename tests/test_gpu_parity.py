@@ -168,6 +168,24 @@ def test_coarse_float_boxes(gpu, rta, scenes, ob, probe_mode):
         _check_hits(g, o)
 
 
+def test_flat_boxes_are_never_entered(gpu, rta, scenes, ob, probe_mode):
+    """scenes.axis_aligned: a mesh in a coordinate plane is invisible to the reference (flat boxes are never
+    entered), a staircase of axis-aligned faces only where its leaves have a volume; the filter tree leaves
+    such triangles out, the reference's trees reject them box by box: same answers either way"""
+    s, cam, flags, orc = _scene_pair(ob, scenes, scenes.axis_aligned)
+    gpu.upload(s)
+    rays = scenes.rays_into_box(30000, 23, (-20, 4, -20), (20, 40, 20), (-12, -6, -12), (12, 6, 12))
+    g, o = gpu.intersect_rays(rays), orc.intersect_rays(rays)
+    assert not np.any(o["obj"] == 2)
+    assert (o["obj"] == 3).sum() > 1000
+    _check_hits(g, o)
+    W = 64
+    p = rta.make_params(W, W, 2, flags=flags)
+    ijk = np.array([(i, j, k) for i in range(0, W, 2) for j in range(0, W, 2) for k in range(2)], np.int32)
+    rel = _rel_err(gpu.sample_radiance(cam, p, ijk), orc.sample_radiance(cam, p, ijk))
+    assert (rel > 1e-9).sum() <= 2, np.sort(rel)[-5:]
+
+
 def test_converged_image_rmse(gpu, rta, scenes, ob):
     """Independent noise: the GPU image at 256 spp (seed 10) against the oracle image at 256 spp with another
     seed, both tone-mapped. The two only share the scene and the estimator, so the RMSE measures bias; the

@@ -64,6 +64,18 @@ def test_axis_aligned_normals_like_the_reference(rta, scenes, ob):
     assert lit >= 2
 
 
+def test_flat_boxes_like_the_reference(rta, scenes, ob):
+    """meshes in coordinate planes: the reference's slab test never reports a box without thickness as hit"""
+    s, cam, o, t = _pair(scenes, ob, scenes.axis_aligned)
+    rays = scenes.rays_into_box(20000, 23, (-20, 4, -20), (20, 40, 20), (-12, -6, -12), (12, 6, 12))
+    ho, ht = o.intersect_rays(rays), t.intersect_rays(rays)
+    assert not np.any(ht["obj"] == 2) and (ht["obj"] == 3).sum() > 500
+    _same_hits(ho, ht)
+    ijk = np.array([(i, j, 0) for i in range(0, 64, 2) for j in range(0, 64, 2)], np.int32)
+    p = rta.make_params(64, 64, 1)
+    assert np.array_equal(o.sample_radiance(cam, p, ijk), t.sample_radiance(cam, p, ijk), equal_nan=True)
+
+
 def test_hit_without_triangle_beyond_1e9(scenes, ob):
     """an unbounded scene whose mesh can only be hit beyond t = 1E9 (raytracer.cpp:689-690, :936)"""
     import importlib
