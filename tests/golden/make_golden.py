@@ -85,6 +85,10 @@ def far_scene():
     return objs, np.ascontiguousarray(np.concatenate([org, d], 1))
 
 
+def axis_rays():
+    return scenes.rays_into_box(4000, 23, (-20, 4, -20), (20, 40, 20), (-12, -6, -12), (12, 6, 12))
+
+
 def main():
     assert ob.have_trueref(), "oracle/_ref/libref_true.so missing: run `make -C oracle` where /root/reference exists"
     out = {}
@@ -125,6 +129,13 @@ def main():
     out["far_no_tri"] = hf["tri"] < 0
     out["far_PNalbedo"] = np.concatenate([hf["P"], hf["N"], hf["albedo"]], 1)
     print("far scene: hits without a triangle:", int(((hf["obj"] == 1) & (hf["tri"] < 0)).sum()), "/", len(rays))
+    # boxes without thickness are never entered (raytracer.cpp:184): scenes.axis_aligned
+    s, cam, _ = scenes.axis_aligned()
+    ha = ob.TrueRefScene(scenes.export_objects(s), s.I, s.L).intersect_rays(axis_rays())
+    out["axis_obj"] = ha["obj"].astype(np.int16)
+    out["axis_tri"] = ha["tri"]
+    out["axis_t"] = ha["t"]
+    print("axis-aligned scene: plane hits", int((ha["obj"] == 2).sum()), " staircase hits", int((ha["obj"] == 3).sum()), "/", len(ha["t"]))
     # tone map (raytracer.cpp:1488-1501) on a value ramp + specials
     acc = (scenes._hash01(np.arange(64 * 64 * 3), 3).reshape(64, 64, 3) ** 4) * 4e5
     acc[0, 0] = (np.nan, -1.0, 0.0)

@@ -80,6 +80,19 @@ def test_hit_without_triangle(gpu, rta, scenes):
     rta.lib.rt_debug_probe_prune(gpu._h, 1)
 
 
+def test_flat_boxes(gpu, rta, scenes):
+    """meshes in coordinate planes against the real reference's answers: a box without thickness is never entered"""
+    mg = importlib.import_module("tests.golden.make_golden")
+    s, cam, _ = scenes.axis_aligned()
+    gpu.upload(s)
+    rays = mg.axis_rays()
+    for prune in (1, 0):
+        rta.lib.rt_debug_probe_prune(gpu._h, prune)
+        h = gpu.intersect_rays(rays)
+        assert np.array_equal(h["obj"], GOLD["axis_obj"]) and np.array_equal(h["tri"], GOLD["axis_tri"]) and np.array_equal(h["t"], GOLD["axis_t"])
+    rta.lib.rt_debug_probe_prune(gpu._h, 1)
+
+
 def test_resolve_matches_reference(gpu, rta, scenes):
     acc = (scenes._hash01(np.arange(64 * 64 * 3), 3).reshape(64, 64, 3) ** 4) * 4e5
     acc[0, 0] = (np.nan, -1.0, 0.0)

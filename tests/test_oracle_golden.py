@@ -94,6 +94,16 @@ def test_hit_without_triangle(scenes, ob):
     _check_far(ob.OracleScene(objs, 1.0, (0, 0, 0)).intersect_rays(rays))
 
 
+def test_flat_boxes(scenes, ob):
+    """meshes in coordinate planes: a box without thickness is never entered (raytracer.cpp:184)"""
+    import importlib
+    mg = importlib.import_module("tests.golden.make_golden")
+    s, cam, _ = scenes.axis_aligned()
+    h = ob.OracleScene(scenes.export_objects(s), s.I, s.L).intersect_rays(mg.axis_rays())
+    assert np.array_equal(h["obj"], GOLD["axis_obj"]) and np.array_equal(h["tri"], GOLD["axis_tri"]) and np.array_equal(h["t"], GOLD["axis_t"])
+    assert not np.any(h["obj"] == 2) and (h["obj"] == 3).sum() > 200
+
+
 def test_resolve(scenes, ob):
     acc = (scenes._hash01(np.arange(64 * 64 * 3), 3).reshape(64, 64, 3) ** 4) * 4e5
     acc[0, 0] = (np.nan, -1.0, 0.0)
