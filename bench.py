@@ -119,6 +119,7 @@ def main():
     r.sync()
     if world > 1:
         dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()  # the resolve below runs on the renderer's own stream: the sum must have landed
     image = None
     if rank == 0:
         image = r.resolve(W, H, args.spp_step * args.steps * world, acc_ptr)

@@ -18,8 +18,12 @@ def total_spp(steps, world, spp_step):
 
 
 def reduce_to_root(accum, world):
-    """sum the per-rank accumulators (torch tensors) onto rank 0; a no-op for one rank"""
+    """sum the per-rank accumulators (torch tensors) onto rank 0; a no-op for one rank. The caller's renders into
+    `accum` must have finished (Renderer.sync()); on return the sum is complete, so it may be resolved on any stream."""
     if world > 1:
+        import torch
         import torch.distributed as dist
         dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        if accum.is_cuda:
+            torch.cuda.synchronize(accum.device)  # the collective is only ordered against torch's current stream
     return accum
