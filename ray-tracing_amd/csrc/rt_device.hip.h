@@ -6,23 +6,33 @@
  * noise-free radiance equal the CPU results bit for bit up to libm differences in cos/sin/log/pow.
  *
  * Execution model: one workgroup = ONE wave of 64 lanes, one lane = one pixel, persistent over its
- * samples.
+ * samples (and, in the render kernel, over the pixels it draws from a global tile counter).
  *   - The recursive Scene::getColor (raytracer.cpp:953-1093) is an iterative state machine with
- *     exactly one closest-hit query per loop iteration. A lane is either on a path segment or on the
- *     shadow ray of its last diffuse vertex; both go through the same query, and a lane whose path
- *     ends starts its next sample at once, so all lanes have a ray in (almost) every iteration.
- *   - The closest-hit query is wave-cooperative. Spheres and the mesh root boxes are tested by each
- *     lane for its own ray (uniform work). Every (ray, BVH record) and (ray, triangle) test after
- *     that is an item in a pool kept in LDS; in each pool step the 64 lanes pop 64 items - whichever
- *     rays they belong to - test them, and push the children that were hit. Lane utilisation no
- *     longer depends on how many of the wave's rays reach a mesh or how deep each goes (a per-lane
- *     traversal ran at 6 % VALU lane utilisation on the battle scene).
- *   - With RT_F_NO_PRUNE the pool visits exactly the BVH records and triangles the reference visits
- *     (every node whose box test passes: raytracer.cpp:652-666), in a different order; by default it
- *     also skips boxes that lie wholly behind the ray's current closest hit, which cannot change the
- *     result. The reference's result depends on order only through exact ties in t, where the first
- *     visited wins; triangles are laid out in that visiting order (see rt_tri in rt_amd.h), so the
- *     tie-break is "lowest position" and the result is order-independent.
+ *     one closest-hit query per loop iteration. A diffuse vertex leaves a shadow ray and an indirect
+ *     ray that do not depend on each other: both go into the same query (two ray slots per lane),
+ *     and a lane whose path ends starts its next sample at once.
+ *   - The closest-hit query is wave-cooperative. Spheres are tested by each lane for its own rays
+ *     (uniform work). Every (ray, BVH record) and (ray, triangle) test after that is an item in a
+ *     pool kept in LDS; in each pool step the 64 lanes pop 64 items - whichever rays they belong
+ *     to - test them, and push the children that were hit. Lane utilisation no longer depends on
+ *     how many of the wave's rays reach a mesh or how deep each goes (a per-lane traversal ran at
+ *     6 % VALU lane utilisation on the battle scene).
+ *   - Which tree is walked: by default a filter tree of this library (rt_own_bvh.hpp: one tree over
+ *     all meshes, four children per record, single-precision boxes rounded outwards), which can only
+ *     say "certainly missed"; its winner is the closest triangle under the reference's tie rule, and
+ *     is accepted once the reference's own leaf box for that triangle is certainly hit (rays_end).
+ *     The few rays for which that cannot be said go round again on the reference's trees.
+ *     With RT_F_NO_PRUNE (and in the counted variant) the pool visits exactly the BVH records and
+ *     triangles the reference visits (every node whose box test passes: raytracer.cpp:652-666), in a
+ *     different order. The reference's result depends on order only through exact ties in t, where
+ *     the first visited wins; triangles are laid out in that visiting order (see rt_tri in rt_amd.h),
+ *     so the tie-break is "lowest position" and the result is order-independent.
+ *   - Box tests run in single precision with a per-ray error bound and decide only what is beyond
+ *     doubt; what they leave open is settled by the reference's six divisions on the FP64 boxes.
+ *     Distance pruning and any-hit shadow rays skip work that cannot change the result.
+ *   - The wave's LDS is kept within an eighth of the CU's 160 KiB (the kernel needs 256 VGPRs, so
+ *     eight waves per CU is the most that can be resident): ray tables hold doubles only where the
+ *     triangle test needs them, and the host picks the node stack's height per scene.
  */
 #pragma once
 #include <hip/hip_runtime.h>
