@@ -206,8 +206,7 @@ def main():
                              "oracle/ref_cpu.cpp with the counter-based RNG" % (args.cpu_spp, dt, threads),
                    "setup_s": round(t2 - t1, 2)}
         if args.out_png and image is not None:
-            from PIL import Image
-            Image.fromarray(image).save(args.out_png)
+            rta.write_png(args.out_png, image)
         out = {"metric": "Mpaths/s (whole node) final scene 1024x1024", "value": round(value, 3), "unit": "Mpaths/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",

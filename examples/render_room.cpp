@@ -2,10 +2,11 @@
  * render_room.cpp - the reference's main() (raytracer.cpp:1153-1515) written against rt_host.hpp: the same
  * object definitions and calls, with the pixel loop replaced by rt::render(). Scene: light + S1/S2/S3 + walls +
  * floor (:1164-1178) and, if an OBJ path is given, one mesh with the rifle soldier's transform chain
- * (:1245-1251). Writes a binary PPM.
- *   render_room <out.ppm> <W> <spp> [mesh.obj [texture.ppm]]
+ * (:1245-1251). Writes a PNG (name ending in .png) or a binary PPM.
+ *   render_room <out.png|out.ppm> <W> <spp> [mesh.obj [texture.ppm]]
  */
 #include <stdio.h>
+#include <string.h>
 #include <stdlib.h>
 
 #include <vector>
@@ -63,11 +64,16 @@ int main(int argc, char **argv) {
         rp.nbrays = atoi(argv[3]);
         std::vector<unsigned char> image;
         render(scene, cam, rp, image);
-        FILE *f = fopen(argv[1], "wb");
-        if (!f) return 3;
-        fprintf(f, "P6\n%d %d\n255\n", W, H);
-        fwrite(&image[0], 1, image.size(), f);
-        fclose(f);
+        const size_t len = strlen(argv[1]);
+        if (len > 4 && strcmp(argv[1] + len - 4, ".png") == 0) { /* as main() ends: raytracer.cpp:1505-1512 */
+            writePNG(argv[1], W, H, &image[0]);
+        } else {
+            FILE *f = fopen(argv[1], "wb");
+            if (!f) return 3;
+            fprintf(f, "P6\n%d %d\n255\n", W, H);
+            fwrite(&image[0], 1, image.size(), f);
+            fclose(f);
+        }
     } catch (const std::exception &e) {
         fprintf(stderr, "error: %s\n", e.what());
         return 1;

@@ -60,6 +60,11 @@ int rth_camera_make(const double C[3], double fov_deg, double angle_v_deg, doubl
                     double dof_sigma, rt_camera *out);
 int rth_params_default(int32_t W, int32_t H, int32_t spp, rt_params *out);
 
+/* the output step of main(), raytracer.cpp:1505-1512: the 8-bit image (rows top to bottom, as rt_resolve returns it) as a
+ * PNG file (stbi_write_png in the reference; same pixels), and the whole seconds of a duration as execution_time.txt has them */
+int rth_write_png(const char *path, int32_t W, int32_t H, const uint8_t *rgb);
+int rth_write_execution_time(const char *path, double seconds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,7 +55,8 @@ RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt
 RTH_SYMBOLS = ["rth_last_error", "rth_mesh_create", "rth_mesh_destroy", "rth_mesh_read_obj", "rth_mesh_load_texture",
                "rth_mesh_add_texture", "rth_mesh_set_raw", "rth_mesh_op", "rth_mesh_build_bvh", "rth_mesh_sizes",
                "rth_mesh_get", "rth_mesh_bvh_dump", "rth_scene_create", "rth_scene_destroy", "rth_scene_add_sphere",
-               "rth_scene_add_mesh", "rth_scene_upload", "rth_scene_flat_info", "rth_camera_make", "rth_params_default"]
+               "rth_scene_add_mesh", "rth_scene_upload", "rth_scene_flat_info", "rth_camera_make", "rth_params_default",
+               "rth_write_png", "rth_write_execution_time"]
 
 _vp, _i32, _i64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 _pd = C.POINTER(C.c_double)
@@ -106,6 +107,8 @@ _sig("rth_scene_upload", C.c_int, _vp, _vp, C.POINTER(_i64))
 _sig("rth_scene_flat_info", C.c_int, _vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64))
 _sig("rth_camera_make", C.c_int, _pd, _dbl, _dbl, _dbl, _i32, _dbl, _dbl, _dbl, C.POINTER(rt_camera))
 _sig("rth_params_default", C.c_int, _i32, _i32, _i32, C.POINTER(rt_params))
+_sig("rth_write_png", C.c_int, C.c_char_p, _i32, _i32, _vp)
+_sig("rth_write_execution_time", C.c_int, C.c_char_p, _dbl)
 
 
 class RTError(RuntimeError):
@@ -367,6 +370,18 @@ class Renderer:
 
     def stream(self):
         return lib.rt_stream(self._h)
+
+
+def write_png(path, image):
+    """The image (H, W, 3) uint8, rows top to bottom, as a PNG file (raytracer.cpp:1506)."""
+    image = np.ascontiguousarray(image, np.uint8)
+    H, W = image.shape[:2]
+    _host_check(lib.rth_write_png(os.fsencode(path), W, H, _ptr(image)))
+
+
+def write_execution_time(path, seconds):
+    """Whole seconds of a duration, as the reference's execution_time.txt has them (raytracer.cpp:1509-1512)."""
+    _host_check(lib.rth_write_execution_time(os.fsencode(path), float(seconds)))
 
 
 def render(scene, cam, W, H, spp, seed=10, flags=0, device=0):

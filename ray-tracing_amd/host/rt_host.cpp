@@ -500,6 +500,81 @@ void render(const Scene &scene, const Camera &cam, const RenderParams &p, std::v
     r.render(cam, p, image);
 }
 
+/* ---- image and timing output (raytracer.cpp:1505-1512) ------------------------------------------------------- */
+namespace {
+struct Crc32 {
+    uint32_t table[256];
+    Crc32() {
+        for (uint32_t n = 0; n < 256; n++) {
+            uint32_t c = n;
+            for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[n] = c;
+        }
+    }
+    uint32_t run(uint32_t crc, const uint8_t *p, size_t n) const {
+        for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+        return crc;
+    }
+};
+void put32(std::vector<uint8_t> &v, uint32_t x) {
+    v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x);
+}
+void png_chunk(std::vector<uint8_t> &out, const char type[4], const std::vector<uint8_t> &data) {
+    static const Crc32 crc;
+    put32(out, (uint32_t)data.size());
+    const size_t at = out.size();
+    out.insert(out.end(), type, type + 4);
+    out.insert(out.end(), data.begin(), data.end());
+    put32(out, crc.run(0xFFFFFFFFu, &out[at], out.size() - at) ^ 0xFFFFFFFFu);
+}
+} // namespace
+
+void writePNG(const char *path, int W, int H, const uint8_t *rgb) {
+    if (!path || !rgb || W <= 0 || H <= 0 || (int64_t)W * H > (int64_t)1 << 28) throw std::runtime_error("writePNG: bad arguments");
+    /* scanlines, each behind a filter byte 0 (none) */
+    const size_t row = (size_t)W * 3;
+    std::vector<uint8_t> raw;
+    raw.reserve((row + 1) * (size_t)H);
+    for (int i = 0; i < H; i++) {
+        raw.push_back(0);
+        raw.insert(raw.end(), rgb + (size_t)i * row, rgb + (size_t)(i + 1) * row);
+    }
+    /* zlib stream of stored deflate blocks (at most 65535 bytes each) + Adler-32 */
+    std::vector<uint8_t> z;
+    z.reserve(raw.size() + raw.size() / 65535 * 5 + 16);
+    z.push_back(0x78); z.push_back(0x01);
+    uint32_t a = 1, b = 0;
+    for (size_t at = 0; at < raw.size();) {
+        const size_t n = std::min<size_t>(65535, raw.size() - at);
+        z.push_back(at + n == raw.size() ? 1 : 0);
+        z.push_back((uint8_t)(n & 0xFF)); z.push_back((uint8_t)(n >> 8));
+        z.push_back((uint8_t)(~n & 0xFF)); z.push_back((uint8_t)((~n >> 8) & 0xFF));
+        z.insert(z.end(), raw.begin() + at, raw.begin() + at + n);
+        for (size_t i = at; i < at + n; i++) { a = (a + raw[i]) % 65521u; b = (b + a) % 65521u; }
+        at += n;
+    }
+    put32(z, (b << 16) | a);
+    std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    std::vector<uint8_t> ihdr;
+    put32(ihdr, (uint32_t)W); put32(ihdr, (uint32_t)H);
+    ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0); /* 8 bits, RGB, deflate, adaptive filters, no interlace */
+    png_chunk(out, "IHDR", ihdr);
+    png_chunk(out, "IDAT", z);
+    png_chunk(out, "IEND", std::vector<uint8_t>());
+    FILE *f = fopen(path, "wb");
+    if (!f) throw std::runtime_error(std::string("writePNG: cannot open ") + path);
+    const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+    if (fclose(f) != 0 || !ok) throw std::runtime_error(std::string("writePNG: write failed: ") + path);
+}
+
+void writeExecutionTime(const char *path, double seconds) {
+    if (!path || !(seconds >= 0)) throw std::runtime_error("writeExecutionTime: bad arguments");
+    FILE *f = fopen(path, "w");
+    if (!f) throw std::runtime_error(std::string("writeExecutionTime: cannot open ") + path);
+    const bool ok = fprintf(f, "%lld", (long long)seconds) > 0; /* (clock() - ini_time) / CLOCKS_PER_SEC is an integer division */
+    if (fclose(f) != 0 || !ok) throw std::runtime_error(std::string("writeExecutionTime: write failed: ") + path);
+}
+
 } // namespace rt
 
 /* ---------------------------------------------------------------------------------------------
@@ -678,5 +753,8 @@ int rth_params_default(int32_t W, int32_t H, int32_t spp, rt_params *out) {
     *out = p.pod();
     return 0;
 }
+
+int rth_write_png(const char *path, int32_t W, int32_t H, const uint8_t *rgb) { RTH_TRY(rt::writePNG(path, W, H, rgb)) }
+int rth_write_execution_time(const char *path, double seconds) { RTH_TRY(rt::writeExecutionTime(path, seconds)) }
 
 } /* extern "C" */

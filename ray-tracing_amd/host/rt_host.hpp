@@ -190,4 +190,11 @@ private:
 /* convenience: one call = what running the reference's main() does up to the PNG write */
 void render(const Scene &scene, const Camera &cam, const RenderParams &p, std::vector<uint8_t> &image, int device = 0);
 
+/* The output step of main(), raytracer.cpp:1505-1512. writePNG stores an 8-bit RGB image (rows top to bottom, as
+ * Renderer::render returns it) as a PNG file: the same pixels as the reference's stbi_write_png call, in an
+ * uncompressed zlib stream (any decoder reads it; the encoder is this library's own). writeExecutionTime writes the
+ * whole seconds of a duration the way the reference writes its execution_time.txt. Both throw on I/O errors. */
+void writePNG(const char *path, int W, int H, const uint8_t *rgb);
+void writeExecutionTime(const char *path, double seconds);
+
 } // namespace rt

@@ -136,3 +136,21 @@ def test_host_against_the_real_reference_on_real_assets(rta, ob):
             assert np.array_equal(a, b), rel
         for a, b in zip(m.bvh_dump(), t.bvh_dump(0)):
             assert np.array_equal(a, b), rel
+
+
+def test_png_and_execution_time_output(rta, tmp_path):
+    """the output step of main() (raytracer.cpp:1505-1512): the PNG decodes to the same pixels, also beyond one 64 KiB block"""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    for H, W in ((1, 1), (37, 53), (300, 200)):
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        path = str(tmp_path / ("o%d.png" % H))
+        rta.write_png(path, img)
+        with Image.open(path) as im:
+            assert im.mode == "RGB" and im.size == (W, H)
+            assert np.array_equal(np.asarray(im), img)
+    rta.write_execution_time(str(tmp_path / "execution_time.txt"), 12.9)
+    assert open(str(tmp_path / "execution_time.txt")).read() == "12"
+    with pytest.raises(rta.RTError):
+        rta.write_png(str(tmp_path / "no_such_dir" / "x.png"), np.zeros((2, 2, 3), np.uint8))
+
