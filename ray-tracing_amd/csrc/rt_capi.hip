@@ -327,6 +327,92 @@ static int32_t ext_split(const rt_tri *tris, int32_t first, int32_t n, std::vect
     return best;
 }
 
+/* The tree over a long sphere list (SphNode in rt_device.hip.h): median cuts of the centres along the widest axis down to
+ * leaves of two spheres, nodes in depth-first order with skip links, spheres re-ordered into leaf order. `reach` is how
+ * far from the coordinate origin a ray may start for the margin of the boxes to hold: a hundred thousand times the
+ * smallest radius, less the largest centre coordinate. (Sphere::intersect accepts delta = b^2 - 4c >= 0 as computed; its
+ * rounding error is below 64 * 2^-53 |C - O|^2, so an accepted ray passes the centre within R sqrt(1 + 16 * 2^-53 |C - O|^2 / R^2)
+ * <= R (1 + 3e-5) when |C - O| <= sqrt(3) * 1e5 R: inside the boxes' margin of R / 1000.) Returns false for a non-finite sphere. */
+static bool build_sphere_tree(const rt_sphere *sph, int n, std::vector<rt_sphere> &sorted, std::vector<SphNode> &nodes, std::vector<double> &boxes_out,
+                              double *reach) {
+    std::vector<int> idx((size_t)n);
+    double rmin = HUGE_VAL, omax = 0;
+    for (int i = 0; i < n; i++) {
+        idx[(size_t)i] = i;
+        if (!std::isfinite(sph[i].R) || !(sph[i].R >= 0)) return false;
+        for (int a = 0; a < 3; a++) {
+            if (!std::isfinite(sph[i].O[a])) return false;
+            if (fabs(sph[i].O[a]) > omax) omax = fabs(sph[i].O[a]);
+        }
+        if (sph[i].R < rmin) rmin = sph[i].R;
+    }
+    *reach = 1e5 * rmin - omax; /* <= 0: every ray tests every sphere */
+    auto sphere_box = [&](int i, double *b) {
+        const double m = sph[i].R * 1.001 + 1e-300;
+        for (int a = 0; a < 3; a++) { b[a] = sph[i].O[a] - m; b[3 + a] = sph[i].O[a] + m; }
+    };
+    /* depth-first emission with an explicit stack: a node is written when it is reached, its skip when its subtree is complete */
+    struct Frame { int node, first, count, stage; };
+    std::vector<Frame> st;
+    st.push_back(Frame{-1, 0, n, 0});
+    while (!st.empty()) {
+        Frame &f = st.back();
+        if (f.stage == 0) {
+            double box[6] = {HUGE_VAL, HUGE_VAL, HUGE_VAL, -HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+            double clo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, chi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+            for (int k = f.first; k < f.first + f.count; k++) {
+                double b[6];
+                sphere_box(idx[(size_t)k], b);
+                for (int a = 0; a < 3; a++) {
+                    if (b[a] < box[a]) box[a] = b[a];
+                    if (b[3 + a] > box[3 + a]) box[3 + a] = b[3 + a];
+                    const double ctr = sph[idx[(size_t)k]].O[a];
+                    if (ctr < clo[a]) clo[a] = ctr;
+                    if (ctr > chi[a]) chi[a] = ctr;
+                }
+            }
+            SphNode nd;
+            memset(&nd, 0, sizeof nd);
+            for (int a = 0; a < 3; a++) {
+                nd.box[a] = nextafterf((float)box[a], -HUGE_VALF);
+                nd.box[3 + a] = nextafterf((float)box[3 + a], HUGE_VALF);
+            }
+            for (int a = 0; a < 6; a++) boxes_out.push_back((double)nd.box[a]);
+            f.node = (int)nodes.size();
+            nodes.push_back(nd);
+            if (f.count <= 2) {
+                nodes[(size_t)f.node].first = f.first;
+                nodes[(size_t)f.node].count = f.count;
+                nodes[(size_t)f.node].skip = f.node + 1;
+                st.pop_back();
+                continue;
+            }
+            int axis = 0;
+            for (int a = 1; a < 3; a++)
+                if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
+            const int half = f.count / 2;
+            std::nth_element(idx.begin() + f.first, idx.begin() + f.first + half, idx.begin() + f.first + f.count,
+                             [&](int x, int y) { return sph[x].O[axis] < sph[y].O[axis] || (sph[x].O[axis] == sph[y].O[axis] && x < y); });
+            f.stage = 1;
+            const Frame left{-1, f.first, half, 0};
+            st.push_back(left); /* invalidates f */
+            continue;
+        }
+        if (f.stage == 1) {
+            f.stage = 2;
+            const int half = f.count / 2;
+            const Frame right{-1, f.first + half, f.count - half, 0};
+            st.push_back(right);
+            continue;
+        }
+        nodes[(size_t)f.node].skip = (int)nodes.size(); /* the node after this subtree */
+        st.pop_back();
+    }
+    sorted.resize((size_t)n);
+    for (int i = 0; i < n; i++) sorted[(size_t)i] = sph[idx[(size_t)i]];
+    return true;
+}
+
 int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
     if (!c) return RT_E_INVALID;
     if (!s) return fail(c, RT_E_INVALID, "rt_upload_scene: scene is NULL");
@@ -410,7 +496,23 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
     int rc;
     int ext_depth = 0, own_depth = 0;
     std::vector<int32_t> ext_root((size_t)s->n_meshes, -1); /* extension record that replaces a mesh's root leaf */
-    if ((rc = upload_array(c, s->spheres, (size_t)s->n_spheres, &d.spheres))) return rc;
+    std::vector<double> sphere_boxes; /* of the sphere tree: they count for the box tests' tolerance like every other box */
+    if (s->n_spheres > RT_LDS_SPHERES_MAX) {
+        /* Long sphere lists: a tree over the spheres' boxes (rt_device.hip.h: SphNode); the spheres go up in its leaf order. */
+        std::vector<rt_sphere> sorted;
+        std::vector<SphNode> nodes;
+        double reach = 0;
+        if (!build_sphere_tree(s->spheres, s->n_spheres, sorted, nodes, sphere_boxes, &reach))
+            return fail(c, RT_E_INVALID, "rt_upload_scene: a sphere has a non-finite centre or radius");
+        if ((rc = upload_array(c, sorted.data(), sorted.size(), &d.spheres))) return rc;
+        if ((rc = upload_array(c, nodes.data(), nodes.size(), &d.sph_nodes))) return rc;
+        d.n_sph_nodes = (int32_t)nodes.size();
+        d.sph_reach = reach;
+        for (size_t k = 0; k + 6 <= sphere_boxes.size(); k += 6) widen(&sphere_boxes[k]);
+        HIPCHK(c, hipStreamSynchronize(c->stream)); /* the staging vectors go out of scope */
+    } else if ((rc = upload_array(c, s->spheres, (size_t)s->n_spheres, &d.spheres))) {
+        return rc;
+    }
     if ((rc = upload_array(c, s->meshes, (size_t)s->n_meshes, &d.meshes))) return rc;
     {
         /* device layouts (rt_device.hip.h): every BVH record as one float record plus two double halves */

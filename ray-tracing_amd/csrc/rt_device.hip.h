@@ -70,6 +70,17 @@ static_assert(RT_NODE_SOFT_MIN > RT_FEED_MARGIN + RT_WAVE && RT_NODE_SOFT_MIN <=
 static_assert(RT_LEAF_CAP >= 5 * RT_WAVE, "a node step adds up to 256 leaf items (filter tree: four children) and runs only when 256 slots are free; a fed mesh adds up to 128 on top of 64");
 #define RT_PHANTOM_BASE (1 << 30)  /* best_pos values from here on: "mesh (value - base) reports a hit without a triangle" */
 
+/* One node of the sphere tree, 48 bytes. Nodes lie in depth-first order: a ray that may touch `box` goes on with the next
+ * node, any other with node `skip`; a leaf (count > 0) holds spheres first .. first + count - 1 and its skip is the next
+ * node. The boxes are the spheres' boxes enlarged by a thousandth of the radius and rounded outwards to float: Sphere::
+ * intersect (raytracer.cpp:883-918) can report a hit for a ray that passes a sphere by a rounding error, which stays
+ * inside that margin as long as the ray starts within a hundred thousand radii (DScene::sph_reach). */
+struct SphNode {
+    float box[6];
+    int32_t skip, first, count;
+    int32_t pad[3];
+};
+
 /* what the root phase needs of a mesh: the root box (raytracer.cpp:644) and where the tree starts */
 struct RootRec { /* 32 bytes; the box rounded to float like NodeRec32, the double box stays in rt_mesh */
     float box[6];
@@ -129,6 +140,11 @@ struct DScene {
     uint32_t n_tris_total, n_nodes_total; /* array lengths: every index taken from the pool is checked against them */
     uint32_t n_ref_nodes;                 /* records below this index are the reference's; the rest are extension records */
     int *overflow;    /* bit 0: a push would have passed a stack's capacity; bit 1: an index outside the arrays */
+    /* Sphere lists too long for LDS: a tree over the spheres' boxes (SphNode, depth-first order with skip links) that a lane
+     * walks without a stack; `spheres` is then in the tree's leaf order. Null for short lists. */
+    const struct SphNode *sph_nodes;
+    int32_t n_sph_nodes, pad_sph;
+    double sph_reach; /* rays whose origin lies farther than this from the coordinate origin (any axis) test every sphere instead */
     double I;
     double L[3];
     double lightO[3];
@@ -432,8 +448,26 @@ struct RayQ {
     bool anyhit;
 };
 
-/* Spheres for one ray (Sphere::intersect, raytracer.cpp:883-918; the lowest objectId wins an exact tie, :938)
- * and the ray's entry in the pool's tables. */
+/* Sphere::intersect, raytracer.cpp:883-918, and Scene::intersect's choice (:938: the lowest objectId wins an exact tie) */
+__device__ __forceinline__ void sphere_test(const rt_sphere *sph, int s, V3 C, V3 u, HitRec &h) {
+    V3 O = ld3(sph[s].O);
+    double R = sph[s].R;
+    int32_t oid = sph[s].object_id;
+    double a = 1;
+    V3 CO = sub(C, O);
+    double b = 2 * dot(u, CO);
+    double c = norm2(CO) - R * R;
+    double delta = b * b - 4 * a * c;
+    if (delta < 0) return;
+    double sq = sqrt(delta);
+    double t2 = (-b + sq) / (2 * a);
+    if (t2 < 0) return;
+    double t1 = (-b - sq) / (2 * a);
+    double t = (t1 > 0) ? t1 : t2;
+    if (t < h.t || (t == h.t && oid < h.obj)) { h.t = t; h.obj = oid; h.prim = s; h.mesh = -1; }
+}
+
+/* Spheres for one ray and the ray's entry in the pool's tables. */
 template <bool CNT>
 __device__ __forceinline__ void ray_begin(const DScene &sc, WaveLDS *w, const rt_sphere *sph, int slot, const RayQ &q, bool prune, HitRec &h, Cnt &cnt) {
     h.t = 1E10;
@@ -446,22 +480,30 @@ __device__ __forceinline__ void ray_begin(const DScene &sc, WaveLDS *w, const rt
     const V3 C = q.C, u = q.u;
     if (CNT) cnt.rays++;
     const int n_sph = uni(sc.n_spheres); /* wave-uniform also when read from LDS */
-    for (int s = 0; s < n_sph; s++) {
-        V3 O = ld3(sph[s].O);
-        double R = sph[s].R;
-        int32_t oid = sph[s].object_id;
-        double a = 1;
-        V3 CO = sub(C, O);
-        double b = 2 * dot(u, CO);
-        double c = norm2(CO) - R * R;
-        double delta = b * b - 4 * a * c;
-        if (delta < 0) continue;
-        double sq = sqrt(delta);
-        double t2 = (-b + sq) / (2 * a);
-        if (t2 < 0) continue;
-        double t1 = (-b - sq) / (2 * a);
-        double t = (t1 > 0) ? t1 : t2;
-        if (t < h.t || (t == h.t && oid < h.obj)) { h.t = t; h.obj = oid; h.prim = s; h.mesh = -1; }
+    const bool walk = sc.sph_nodes != nullptr && prune && fabs(C.x) < sc.sph_reach && fabs(C.y) < sc.sph_reach && fabs(C.z) < sc.sph_reach;
+    if (sc.sph_nodes != nullptr && walk) {
+        /* Long sphere lists: only the spheres whose (enlarged) boxes the ray may touch, and that can still matter - nearer
+         * than the closest hit so far and than tmax -, get the test below; the winner is the same, because the choice
+         * among tested spheres (smallest t, then smallest objectId) does not depend on their order. */
+        const RayK k = ray_constants(sc, C, u);
+        RayKf kf;
+        kf.iux = (float)k.iu.x; kf.iuy = (float)k.iu.y; kf.iuz = (float)k.iu.z;
+        kf.ncx = (float)k.nc.x; kf.ncy = (float)k.nc.y; kf.ncz = (float)k.nc.z;
+        kf.tol = (float)(k.tol * RT_TOLF_SCALE);
+        const int n_nodes = sc.n_sph_nodes;
+        int i = 0;
+        for (int guard = 0; i < n_nodes && guard <= n_nodes; guard++) {
+            const SphNode nd = sc.sph_nodes[i];
+            bool hit, unsure;
+            float tlo;
+            box_fast_f(nd.box[0], nd.box[1], nd.box[2], nd.box[3], nd.box[4], nd.box[5], kf, hit, unsure, tlo);
+            const double bound = h.t < q.tmax ? h.t : q.tmax;
+            if (!(hit || unsure) || (double)tlo > bound) { i = nd.skip; continue; } /* certainly missed, or wholly behind what is known */
+            for (int s = nd.first; s < nd.first + nd.count; s++) sphere_test(sph, s, C, u, h);
+            i++;
+        }
+    } else {
+        for (int s = 0; s < n_sph; s++) sphere_test(sph, s, C, u, h);
     }
     if (sc.n_meshes == 0) return;
     /* Mesh hits are accepted only below t0 = min(1E9, sphere hit, tmax): TriangleMesh::intersect starts at

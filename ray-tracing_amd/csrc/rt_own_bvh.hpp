@@ -55,7 +55,10 @@ static inline void box_to_float(const Bounds &b, float *box) { /* rounded outwar
     }
 }
 
-static const int kBins = 16;
+#ifndef RT_OWN_BINS
+#define RT_OWN_BINS 16
+#endif
+static const int kBins = RT_OWN_BINS;
 #ifndef RT_OWN_LEAF
 #define RT_OWN_LEAF 4
 #endif

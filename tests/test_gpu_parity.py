@@ -236,9 +236,10 @@ def test_stochastic_per_sample(gpu, rta, scenes, ob, name, kw):
     assert bad <= max(2, len(ijk) // 2000), (bad, len(ijk), np.sort(rel)[-5:])
 
 
-def test_many_spheres_and_one_big_mesh(gpu, rta, scenes, ob):
-    """cfg5 at reduced size: more spheres than the per-wave LDS staging holds (so they are read from
-    global memory) of all three materials, plus one mesh: hits bit-exact, per-sample radiance as above"""
+def test_many_spheres_and_one_big_mesh(gpu, rta, scenes, ob, probe_mode):
+    """cfg5 at reduced size: more spheres than the per-wave LDS staging holds - they are reached through a tree
+    over their boxes (every sphere is tested when pruning is off) - of all three materials, plus one mesh:
+    hits bit-exact, per-sample radiance as above"""
     W = 96
     s, cam, flags, orc = _scene_pair(ob, scenes, scenes.stress, W=W, n_tris=60000, n_spheres=150)
     assert s.flat_info()["n_spheres"] > 64
