@@ -236,13 +236,14 @@ def test_stochastic_per_sample(gpu, rta, scenes, ob, name, kw):
     assert bad <= max(2, len(ijk) // 2000), (bad, len(ijk), np.sort(rel)[-5:])
 
 
-def test_many_spheres_and_one_big_mesh(gpu, rta, scenes, ob, probe_mode):
+@pytest.mark.parametrize("n_spheres", [58, 59, 150])  # 64 objects in all: the longest list staged in LDS; 65 and 156: the tree
+def test_many_spheres_and_one_big_mesh(gpu, rta, scenes, ob, probe_mode, n_spheres):
     """cfg5 at reduced size: more spheres than the per-wave LDS staging holds - they are reached through a tree
     over their boxes (every sphere is tested when pruning is off) - of all three materials, plus one mesh:
     hits bit-exact, per-sample radiance as above"""
     W = 96
-    s, cam, flags, orc = _scene_pair(ob, scenes, scenes.stress, W=W, n_tris=60000, n_spheres=150)
-    assert s.flat_info()["n_spheres"] > 64
+    s, cam, flags, orc = _scene_pair(ob, scenes, scenes.stress, W=W, n_tris=60000 if n_spheres == 150 else 8000, n_spheres=n_spheres)
+    assert s.flat_info()["n_spheres"] == n_spheres + 6
     gpu.upload(s)
     rays, _ = ob.primary_rays(cam, W, W)
     g, o = gpu.intersect_rays(rays), orc.intersect_rays(rays)
