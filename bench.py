@@ -105,6 +105,11 @@ def main():
     for w in range(args.warmup):
         step(w)
     r.sync()
+    if world > 1 and args.warmup > 0:
+        # the timed region ends with one sum-reduction of the accumulator: let RCCL set up its connections for
+        # that collective and size outside it, as the warm-up steps do for the kernel
+        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
     accum.zero_()
     barrier()
 
