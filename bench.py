@@ -73,9 +73,17 @@ def main():
     import torch
     import torch.distributed as dist
 
+    # RT_BENCH_BACKEND=gloo is for rehearsing the multi-rank path on a box with fewer GPUs than ranks (ranks then share
+    # devices, which RCCL refuses); the measured configuration is one GPU per rank over RCCL.
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     rta = importlib.import_module("ray-tracing_amd")
     scenes = importlib.import_module("ray-tracing_amd.scenes")
@@ -219,7 +227,7 @@ def main():
                                       "textures, DoF sigma 0.01), %dx%d, %d spp per rank per step; time-to-image at 1000 spp "
                                       "extrapolates to %.2f s on this many GPUs" % (info["n_tris"], info["n_nodes"], W, H, args.spp_step,
                                                                                       1000.0 * W * H / (value * 1e6)),
-                          "spp_per_step": args.spp_step, "parallelism": "spp-sharded x%d + RCCL reduce(sum) of the f64 accumulator" % world,
+                          "spp_per_step": args.spp_step, "parallelism": "spp-sharded x%d + %s reduce(sum) of the f64 accumulator" % (world, "RCCL" if backend == "nccl" else backend),
                           "scene_bytes_hbm": info["bytes"], "scene_bytes_device": sizes[0], "traversal_records": sizes[1],
                           "filter_tree_records": sizes[2], "waves_per_cu": min(occ_b.value, 8), "lds_bytes_per_wave": occ_l.value,
                           "setup_s": round(setup_s, 2)},
