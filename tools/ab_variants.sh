@@ -4,6 +4,8 @@ cd $GRAFT_REPO_ROOT
 L=ray-tracing_amd/csrc/librt_amd.so
 cp $L /tmp/base.so
 mkdir -p gpurun_out/ab
+# the first run on a fresh box is ~2 % slower than the following ones: one discarded run first
+timeout -k 10 200 python -u bench.py --no-cpu-baseline --steps 2 --spp-step ${SPP:-16} > gpurun_out/ab/warmup.log 2>&1 || { echo "warm-up FAILED"; tail -3 gpurun_out/ab/warmup.log; exit 1; }
 for v in base "$@"; do
   if [ $v = base ]; then cp /tmp/base.so $L; else cp ray-tracing_amd/csrc/variants/$v.so $L; fi
   timeout -k 10 200 python -u bench.py --no-cpu-baseline --steps 3 --spp-step ${SPP:-16} > gpurun_out/ab/$v.log 2>&1 || { echo "$v FAILED"; tail -3 gpurun_out/ab/$v.log; exit 1; }
