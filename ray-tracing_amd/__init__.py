@@ -160,7 +160,7 @@ class TriangleMesh:
         self.textures = []
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:  # at interpreter shutdown the module's globals may be gone already
             lib.rth_mesh_destroy(self._h)
             self._h = None
 
@@ -293,7 +293,7 @@ class Renderer:
         self.flat_bytes = 0
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:  # at interpreter shutdown the module's globals may be gone already
             lib.rt_destroy(self._h)
             self._h = None
 
