@@ -254,6 +254,21 @@ int rt_last_render_ms(rt_ctx *ctx, double *ms, int32_t *n_launches);
  * want to order their own work after a render. */
 void *rt_stream(rt_ctx *ctx);
 
+/* TriangleMesh::buildBVH (raytracer.cpp:220-291) on the GPU, with the reference's result: the same boxes, the same
+ * tree and the same order of the triangles. verts = nv * 3 doubles, tri_vtx = nt * 3 vertex indices (vtxi, vtxj, vtxk of
+ * TriangleIndices), both HOST pointers. order (nt entries) receives, for every position of the permuted triangle array,
+ * the index of the triangle that the loop of :268-278 has moved there; nodes (node_cap entries; 2 * nt + 1 always
+ * suffice) receives the Noeud records in the order the reference's recursion creates them (node 0 = root, a node's
+ * children get the next two numbers when it is split); n_nodes their count. Synchronous. */
+typedef struct rt_build_node {
+    double box[6];       /* b.mini, b.maxi */
+    int32_t debut, fin;  /* range in the permuted triangle array */
+    int32_t fg, fd;      /* children, -1 for a leaf */
+    int32_t depth, pad;
+} rt_build_node; /* 72 bytes */
+int rt_build_bvh(rt_ctx *ctx, const double *verts, int64_t nv, const int32_t *tri_vtx, int64_t nt, int32_t *order,
+                 rt_build_node *nodes, int64_t node_cap, int64_t *n_nodes);
+
 /* Library version / build info string. */
 const char *rt_version(void);
 

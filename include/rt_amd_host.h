@@ -39,6 +39,8 @@ int rth_mesh_set_raw(rth_mesh *m, int64_t nv, const double *v, int64_t nn, const
 int rth_mesh_op(rth_mesh *m, int op, int a, int b, double angle);
 /* buildBVH(BVH, 0, indices.size()), raytracer.cpp:244, :1385 */
 int rth_mesh_build_bvh(rth_mesh *m);
+/* the same on the GPU of ctx (rt_build_bvh of rt_amd.h): identical boxes, tree and triangle order */
+int rth_mesh_build_bvh_device(rth_mesh *m, rt_ctx *ctx);
 int rth_mesh_sizes(const rth_mesh *m, int64_t *nv, int64_t *nn, int64_t *nuv, int64_t *nt, int32_t *ntex, int64_t *n_nodes, int32_t *max_depth);
 /* current arrays (any may be NULL); perm[k] = face-fan index of the triangle now at position k */
 int rth_mesh_get(const rth_mesh *m, double *v, double *n, double *uv, int32_t *idx10, int32_t *perm);

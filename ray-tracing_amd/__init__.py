@@ -51,9 +51,9 @@ class rt_counters(C.Structure):
 # every symbol include/rt_amd.h and include/rt_amd_host.h declare
 RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_render", "rt_sync", "rt_accum_clear",
               "rt_accum_download", "rt_accum_upload", "rt_accum_device_ptr", "rt_resolve", "rt_intersect_rays", "rt_sample_radiance",
-              "rt_get_counters", "rt_reset_counters", "rt_last_render_ms", "rt_stream", "rt_version"]
+              "rt_get_counters", "rt_reset_counters", "rt_last_render_ms", "rt_stream", "rt_version", "rt_build_bvh"]
 RTH_SYMBOLS = ["rth_last_error", "rth_mesh_create", "rth_mesh_destroy", "rth_mesh_read_obj", "rth_mesh_load_texture",
-               "rth_mesh_add_texture", "rth_mesh_set_raw", "rth_mesh_op", "rth_mesh_build_bvh", "rth_mesh_sizes",
+               "rth_mesh_add_texture", "rth_mesh_set_raw", "rth_mesh_op", "rth_mesh_build_bvh", "rth_mesh_build_bvh_device", "rth_mesh_sizes",
                "rth_mesh_get", "rth_mesh_bvh_dump", "rth_scene_create", "rth_scene_destroy", "rth_scene_add_sphere",
                "rth_scene_add_mesh", "rth_scene_upload", "rth_scene_flat_info", "rth_camera_make", "rth_params_default",
                "rth_write_png", "rth_write_execution_time"]
@@ -95,6 +95,7 @@ _sig("rth_mesh_add_texture", C.c_int, _vp, _vp, _i32, _i32)
 _sig("rth_mesh_set_raw", C.c_int, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp)
 _sig("rth_mesh_op", C.c_int, _vp, C.c_int, C.c_int, C.c_int, _dbl)
 _sig("rth_mesh_build_bvh", C.c_int, _vp)
+_sig("rth_mesh_build_bvh_device", C.c_int, _vp, _vp)
 _sig("rth_mesh_sizes", C.c_int, _vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32),
      C.POINTER(_i64), C.POINTER(_i32))
 _sig("rth_mesh_get", C.c_int, _vp, _vp, _vp, _vp, _vp, _vp)
@@ -216,8 +217,12 @@ class TriangleMesh:
     def zoom(self, k):
         return self._op("zoom", 0, int(k))  # int argument: zoom(0.8) == zoom(0), raytracer.cpp:840, :1285
 
-    def buildBVH(self):
-        _host_check(lib.rth_mesh_build_bvh(self._h))
+    def buildBVH(self, renderer=None):
+        """TriangleMesh::buildBVH (raytracer.cpp:244-291) on the host, or on the GPU of `renderer`: same result."""
+        if renderer is None:
+            _host_check(lib.rth_mesh_build_bvh(self._h))
+        else:
+            _host_check(lib.rth_mesh_build_bvh_device(self._h, renderer._h))
         return self
 
     def sizes(self):

@@ -942,3 +942,5 @@ int rt_reset_counters(rt_ctx *c) {
 }
 
 } /* extern "C" */
+
+#include "rt_bvh_build.hip.h"

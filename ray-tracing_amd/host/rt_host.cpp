@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <memory>
 
 namespace rt {
 
@@ -280,6 +281,34 @@ void TriangleMesh::buildBVH() {
     bvh.reserve(2 * indices.size() + 1);
     bvh.push_back(BVHNode());
     buildNode(0, 0, (int)indices.size(), 0);
+}
+
+void TriangleMesh::buildBVH(rt_ctx *ctx) {
+    if (!ctx) throw std::runtime_error("buildBVH: no context");
+    const size_t nt = indices.size(), nv = vertices.size();
+    if (nt == 0) throw std::runtime_error("buildBVH: the mesh has no triangles");
+    std::vector<double> v(nv * 3);
+    for (size_t i = 0; i < nv; i++)
+        for (int k = 0; k < 3; k++) v[3 * i + k] = vertices[i][k];
+    std::vector<int32_t> tv(nt * 3), ord(nt);
+    for (size_t i = 0; i < nt; i++) { tv[3 * i] = indices[i].vtxi; tv[3 * i + 1] = indices[i].vtxj; tv[3 * i + 2] = indices[i].vtxk; }
+    const size_t cap = 2 * nt + 1;
+    std::unique_ptr<rt_build_node[]> nodes(new rt_build_node[cap]); /* not zero-filled: 72 bytes per possible node */
+    int64_t n_nodes = 0;
+    if (rt_build_bvh(ctx, v.data(), (int64_t)nv, tv.data(), (int64_t)nt, ord.data(), nodes.get(), (int64_t)cap, &n_nodes) != RT_OK)
+        throw std::runtime_error(std::string("buildBVH: ") + rt_last_error(ctx));
+    std::vector<TriangleIndices> moved(nt);
+    order.resize(nt);
+    for (size_t k = 0; k < nt; k++) { moved[k] = indices[(size_t)ord[k]]; order[k] = ord[k]; }
+    indices.swap(moved);
+    bvh.resize((size_t)n_nodes);
+    for (int64_t q = 0; q < n_nodes; q++) {
+        BVHNode &n = bvh[(size_t)q];
+        for (int k = 0; k < 6; k++) n.box[k] = nodes[(size_t)q].box[k];
+        n.debut = nodes[(size_t)q].debut; n.fin = nodes[(size_t)q].fin;
+        n.fg = nodes[(size_t)q].fg; n.fd = nodes[(size_t)q].fd;
+        n.depth = nodes[(size_t)q].depth;
+    }
 }
 
 int TriangleMesh::maxDepth() const {
@@ -642,6 +671,7 @@ int rth_mesh_op(rth_mesh *h, int op, int a, int b, double angle) {
 }
 
 int rth_mesh_build_bvh(rth_mesh *h) { RTH_TRY(h->m.buildBVH()) }
+int rth_mesh_build_bvh_device(rth_mesh *h, rt_ctx *ctx) { RTH_TRY(h->m.buildBVH(ctx)) }
 
 int rth_mesh_sizes(const rth_mesh *h, int64_t *nv, int64_t *nn, int64_t *nuv, int64_t *nt, int32_t *ntex, int64_t *n_nodes, int32_t *max_depth) {
     if (nv) *nv = (int64_t)h->m.vertices.size();

@@ -107,6 +107,8 @@ public:
     void zoom(int zoomFacteur);
     /* buildBVH(BVH, 0, indices.size()) of the reference: permutes `indices` and fills `bvh` */
     void buildBVH();
+    /* the same on the GPU of `ctx` (rt_build_bvh): identical boxes, tree and triangle order */
+    void buildBVH(rt_ctx *ctx);
 
     std::vector<TriangleIndices> indices;
     std::vector<Vector> vertices;

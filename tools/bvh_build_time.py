@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Diagnostic: time of TriangleMesh::buildBVH on the host and on the GPU for a procedural mesh of n triangles."""
+import importlib, os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+rta = importlib.import_module("ray-tracing_amd"); scenes = importlib.import_module("ray-tracing_amd.scenes")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+g = scenes.grid_for_triangles(n)
+v, nn, uv, ix = scenes.blob_mesh(g, size=(40.0, 6.0, 40.0), offset=(0.0, -14.0, -10.0), seed=12345, bump=0.3)
+r = rta.Renderer(0)
+out = {"n_tris": len(ix)}
+for name, arg in (("host", None), ("gpu", r), ("gpu_again", r)):
+    m = rta.TriangleMesh((1, 1, 1)); m.set_raw(v, nn, uv, ix)
+    t = time.time(); m.buildBVH(arg); out[name + "_s"] = round(time.time() - t, 3)
+    out[name + "_nodes"] = m.sizes()["n_nodes"]
+    if name == "host":
+        ref = m.arrays()[4].copy()
+    else:
+        out[name + "_same_order"] = bool(np.array_equal(ref, m.arrays()[4]))
+print(json.dumps(out))
+r.close()
