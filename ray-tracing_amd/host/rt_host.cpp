@@ -6,6 +6,7 @@
 #include "rt_host.hpp"
 
 #include <math.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -301,14 +302,11 @@ void TriangleMesh::buildBVH(rt_ctx *ctx) {
     order.resize(nt);
     for (size_t k = 0; k < nt; k++) { moved[k] = indices[(size_t)ord[k]]; order[k] = ord[k]; }
     indices.swap(moved);
-    bvh.resize((size_t)n_nodes);
-    for (int64_t q = 0; q < n_nodes; q++) {
-        BVHNode &n = bvh[(size_t)q];
-        for (int k = 0; k < 6; k++) n.box[k] = nodes[(size_t)q].box[k];
-        n.debut = nodes[(size_t)q].debut; n.fin = nodes[(size_t)q].fin;
-        n.fg = nodes[(size_t)q].fg; n.fd = nodes[(size_t)q].fd;
-        n.depth = nodes[(size_t)q].depth;
-    }
+    static_assert(sizeof(BVHNode) == sizeof(rt_build_node) && offsetof(BVHNode, debut) == offsetof(rt_build_node, debut) &&
+                      offsetof(BVHNode, fg) == offsetof(rt_build_node, fg) && offsetof(BVHNode, depth) == offsetof(rt_build_node, depth),
+                  "the two node records have the same layout");
+    const BVHNode *first = reinterpret_cast<const BVHNode *>(nodes.get());
+    bvh.assign(first, first + n_nodes);
 }
 
 int TriangleMesh::maxDepth() const {

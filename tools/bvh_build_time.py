@@ -17,5 +17,16 @@ for name, arg in (("host", None), ("gpu", r), ("gpu_again", r)):
         ref = m.arrays()[4].copy()
     else:
         out[name + "_same_order"] = bool(np.array_equal(ref, m.arrays()[4]))
+# the C entry point alone (no mesh object around it)
+import ctypes as C
+tv = np.ascontiguousarray(ix[:, 0:3], np.int32); vv = np.ascontiguousarray(v, np.float64)
+order = np.empty(len(tv), np.int32); nodes = np.empty((2 * len(tv) + 1) * 72, np.uint8); nn_ = C.c_int64()
+rta.lib.rt_build_bvh.restype = C.c_int
+for rep in range(2):
+    t = time.time()
+    rc = rta.lib.rt_build_bvh(r._h, vv.ctypes.data_as(C.c_void_p), C.c_int64(len(vv)), tv.ctypes.data_as(C.c_void_p), C.c_int64(len(tv)),
+                              order.ctypes.data_as(C.c_void_p), nodes.ctypes.data_as(C.c_void_p), C.c_int64(2 * len(tv) + 1), C.byref(nn_))
+    out["c_abi_s"] = round(time.time() - t, 3)
+out["c_abi_rc"] = rc; out["c_abi_same_order"] = bool(np.array_equal(order, ref))
 print(json.dumps(out))
 r.close()
