@@ -5,9 +5,10 @@
  *
  * The reference builds depth first; here all nodes of one depth are processed together ("level"), which gives the
  * same tree because a node's work depends only on its own range [debut, fin). Per level, for every open node:
- *   1. box of the range (:220-242): minima / maxima are order-independent except for the sign of a zero, so a node
- *      with a zero box coordinate gets its box recomputed on the host in the reference's order;
- *   2. the axis and the middle of the box (:250-267), on the host (a few numbers per node);
+ *   1. box of the range (:220-242): minima / maxima are order-independent except for the sign of a zero: std::min and
+ *      std::max keep the first of two equal values, so a zero minimum or maximum has the sign of the first zero the
+ *      loop meets along that axis, which a second pass finds (smallest position, then vertex slot);
+ *   2. the axis and the middle of the box (:250-267);
  *   3. the partition loop (:268-278) "for i: if centre(i) < middle: swap(a[i], a[pivot]); pivot++". Its result is
  *      not a stable partition: with S = "centre < middle" and U = the rest,
  *        - the S elements end up in front in their original order;
@@ -17,10 +18,16 @@
  *      V[number of rotations so far] - the queue at the end is the last |U| entries of V. Which slot of V a position
  *      writes, and which earlier slot a copy refers to, follow from prefix sums of S over the positions; the copies
  *      are resolved by pointer jumping (log2 of the largest range rounds).
- *   4. the split rule (:283), on the host: the level's nodes that go on form the next level.
+ *   4. the split rule (:283): the nodes that go on get their two children appended to the node array (places from a
+ *      prefix sum over the level), and these form the next level.
+ * Everything of a level stays on the device; the host reads three numbers per level (nodes of the next level, the
+ * largest of their ranges, an error flag) and the finished tree at the end, which it renumbers into the order in which
+ * the reference's recursion creates the nodes.
  */
 #pragma once
 #include <rocprim/rocprim.hpp>
+
+#include <memory>
 
 namespace rtbuild {
 
@@ -30,13 +37,6 @@ __device__ __forceinline__ unsigned long long key_of(double d) {
     const unsigned long long b = (unsigned long long)__double_as_longlong(d);
     return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
-static inline double value_of(unsigned long long k) {
-    const unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
-    double d;
-    memcpy(&d, &b, 8);
-    return d;
-}
-
 struct LevelNode { /* one open node of the current level, as the kernels see it */
     int32_t debut, fin;
     int32_t dim;      /* axis of the cut */
@@ -59,11 +59,6 @@ __device__ __forceinline__ int node_at(const LevelNode *nd, int n_nodes, int pos
 __global__ void k_node_of(const LevelNode *nd, int n_nodes, int n, int32_t *node_of) {
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
     if (pos < n) node_of[pos] = node_at(nd, n_nodes, pos);
-}
-
-__global__ void k_box_init(unsigned long long *keys, int n_nodes) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < n_nodes * 6) keys[q] = key_of((q % 6) < 3 ? 1E9 : -1E9); /* :223-224 */
 }
 
 /* minima and maxima of the vertices of the triangles of every open node */
@@ -188,6 +183,116 @@ __global__ void k_back(const int32_t *node_of, const LevelNode *nd, int n, const
     perm2[pos] = -1 - v;
 }
 
+
+__device__ __forceinline__ double dvalue_of(unsigned long long k) {
+    const unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+struct LevelInfo { /* what the host reads after a level */
+    int32_t m_next, largest_next, unresolved, pad;
+};
+
+/* the open nodes of this level as the kernels want them, their boxes at the start values of :223-224 */
+__global__ void k_level_init(const int32_t *open, int m, const rt_build_node *T, LevelNode *nd, unsigned long long *keys, unsigned long long *zfirst) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= m) return;
+    const rt_build_node &t = T[open[q]];
+    LevelNode d;
+    d.debut = t.debut; d.fin = t.fin; d.dim = 0; d.lead = -1; d.base_s = 0; d.n_s = 0; d.milieu = 0;
+    nd[q] = d;
+    for (int a = 0; a < 3; a++) {
+        keys[(size_t)q * 6 + a] = key_of(1E9);
+        keys[(size_t)q * 6 + 3 + a] = key_of(-1E9);
+        zfirst[(size_t)q * 3 + a] = ~0ull;
+    }
+}
+
+/* for the axes along which a node's minimum or maximum is zero: the first zero coordinate in the loop's order
+ * (position, then vertex slot) and its sign bit */
+__global__ void k_zero_first(const double *verts, const int32_t *tri_vtx, const int32_t *perm, const int32_t *node_of, int n, const unsigned long long *keys,
+                             unsigned long long *zfirst) {
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= n) return;
+    const int node = node_of[pos];
+    if (node < 0) return;
+    const unsigned long long kz = key_of(0.0);
+    for (int a = 0; a < 3; a++) {
+        if (keys[(size_t)node * 6 + a] != kz && keys[(size_t)node * 6 + 3 + a] != kz) continue;
+        const int t = perm[pos];
+        for (int slot = 0; slot < 3; slot++) {
+            const double x = verts[(size_t)tri_vtx[3 * (size_t)t + slot] * 3 + a];
+            if (x == 0.0) {
+                const unsigned long long sign = (unsigned long long)__double_as_longlong(x) >> 63;
+                atomicMin(zfirst + (size_t)node * 3 + a, ((((unsigned long long)pos << 2) | (unsigned long long)slot) << 1) | sign);
+                break; /* later slots of this triangle come later in the loop */
+            }
+        }
+    }
+}
+
+/* box, axis and middle of every open node (:246-267) */
+__global__ void k_axis(const int32_t *open, int m, const unsigned long long *keys, const unsigned long long *zfirst, rt_build_node *T, LevelNode *nd) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= m) return;
+    double box[6];
+    for (int a = 0; a < 6; a++) {
+        box[a] = dvalue_of(keys[(size_t)q * 6 + a]);
+        if (box[a] == 0.0) {
+            const unsigned long long z = zfirst[(size_t)q * 3 + (a % 3)];
+            box[a] = (z != ~0ull && (z & 1ull)) ? -0.0 : 0.0;
+        }
+    }
+    rt_build_node &t = T[open[q]];
+    for (int a = 0; a < 6; a++) t.box[a] = box[a];
+    const double dx = box[3] - box[0], dy = box[4] - box[1], dz = box[5] - box[2];
+    int dim;
+    if (dx >= dy && dx >= dz) dim = 0;
+    else if (dy >= dx && dy >= dz) dim = 1;
+    else dim = 2;
+    nd[q].dim = dim;
+    nd[q].milieu = (box[dim] + box[3 + dim]) * 0.5;
+}
+
+/* :283 - which open nodes are split */
+__global__ void k_split_flags(const LevelNode *nd, int m, int32_t *flag) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= m) return;
+    const LevelNode d = nd[q];
+    const int pivot = d.debut + d.n_s;
+    flag[q] = (pivot == d.debut || pivot == d.fin || d.fin - d.debut < 5) ? 0 : 1;
+}
+
+/* the children of the nodes that are split: appended to the node array in the level's order, two per node */
+__global__ void k_split_apply(const LevelNode *nd, int m, const int32_t *flag, const int32_t *rank, const int32_t *open, int tree_count, rt_build_node *T,
+                              int32_t *open_next, LevelInfo *info) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= m) return;
+    if (q == m - 1) info->m_next = 2 * (rank[q] + flag[q]);
+    if (!flag[q]) return;
+    const LevelNode d = nd[q];
+    const int pivot = d.debut + d.n_s, id = open[q], l = tree_count + 2 * rank[q];
+    rt_build_node a, b;
+    for (int k = 0; k < 6; k++) a.box[k] = b.box[k] = 0;
+    a.debut = d.debut; a.fin = pivot; b.debut = pivot; b.fin = d.fin;
+    a.fg = a.fd = b.fg = b.fd = -1;
+    a.depth = b.depth = T[id].depth + 1;
+    a.pad = b.pad = 0;
+    T[l] = a;
+    T[l + 1] = b;
+    T[id].fg = l;
+    T[id].fd = l + 1;
+    open_next[2 * rank[q]] = l;
+    open_next[2 * rank[q] + 1] = l + 1;
+    const int big = (pivot - d.debut) > (d.fin - pivot) ? (pivot - d.debut) : (d.fin - pivot);
+    atomicMax(&info->largest_next, big);
+}
+
+__global__ void k_iota(int32_t *p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+
 struct DeviceArrays { /* device allocations of one build, released when it ends */
     std::vector<void *> p;
     ~DeviceArrays() { for (void *q : p) (void)hipFree(q); }
@@ -197,11 +302,6 @@ struct DeviceArrays { /* device allocations of one build, released when it ends 
         p.push_back(q);
         return (T *)q;
     }
-};
-
-struct TreeNode { /* host side: a node of the result, in the numbering of the reference's recursion */
-    double box[6];
-    int debut, fin, fg, fd, depth;
 };
 
 } // namespace rtbuild
@@ -218,85 +318,43 @@ extern "C" int rt_build_bvh(rt_ctx *c, const double *verts, int64_t nv, const in
     HIPCHK(c, hipSetDevice(c->device));
     const int n = (int)nt;
     DeviceArrays dev;
+    const int64_t cap_dev = 2 * nt + 1;
     double *d_verts = dev.get<double>((size_t)nv * 3);
     int32_t *d_tri = dev.get<int32_t>((size_t)nt * 3), *d_perm = dev.get<int32_t>(n), *d_perm2 = dev.get<int32_t>(n), *d_node_of = dev.get<int32_t>(n),
-            *d_flag = dev.get<int32_t>(n), *d_scan = dev.get<int32_t>(n), *d_V = dev.get<int32_t>(n), *d_unres = dev.get<int32_t>(1);
+            *d_flag = dev.get<int32_t>(n), *d_scan = dev.get<int32_t>(n), *d_V = dev.get<int32_t>(n), *d_open = dev.get<int32_t>(n), *d_open2 = dev.get<int32_t>(n),
+            *d_sflag = dev.get<int32_t>(n), *d_srank = dev.get<int32_t>(n);
     LevelNode *d_nd = dev.get<LevelNode>(n);
-    unsigned long long *d_keys = dev.get<unsigned long long>((size_t)n * 6);
+    LevelInfo *d_info = dev.get<LevelInfo>(1);
+    unsigned long long *d_keys = dev.get<unsigned long long>((size_t)n * 6), *d_zfirst = dev.get<unsigned long long>((size_t)n * 3);
+    rt_build_node *d_T = dev.get<rt_build_node>((size_t)cap_dev);
     size_t tmp_bytes = 0;
     (void)rocprim::exclusive_scan(nullptr, tmp_bytes, d_flag, d_scan, 0, (size_t)n, rocprim::plus<int32_t>(), c->stream);
     void *d_tmp = dev.get<char>(tmp_bytes);
-    if (!d_verts || !d_tri || !d_perm || !d_perm2 || !d_node_of || !d_flag || !d_scan || !d_V || !d_unres || !d_nd || !d_keys || !d_tmp)
+    if (!d_verts || !d_tri || !d_perm || !d_perm2 || !d_node_of || !d_flag || !d_scan || !d_V || !d_open || !d_open2 || !d_sflag || !d_srank || !d_nd || !d_info ||
+        !d_keys || !d_zfirst || !d_T || !d_tmp)
         return fail(c, RT_E_NOMEM, "rt_build_bvh: device allocation failed");
+    const int B = 256, G = (n + B - 1) / B;
     HIPCHK(c, hipMemcpyAsync(d_verts, verts, (size_t)nv * 24, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_tri, tri_vtx, (size_t)nt * 12, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_iota, dim3(G), dim3(B), 0, c->stream, d_perm, n);
     {
-        std::vector<int32_t> ident((size_t)n);
-        for (int i = 0; i < n; i++) ident[(size_t)i] = i;
-        HIPCHK(c, hipMemcpyAsync(d_perm, ident.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        rt_build_node root;
+        memset(&root, 0, sizeof root);
+        root.debut = 0; root.fin = n; root.fg = root.fd = -1; root.depth = 0;
+        const int32_t zero = 0;
+        HIPCHK(c, hipMemcpyAsync(d_T, &root, sizeof root, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_open, &zero, 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream)); /* root and zero are locals */
     }
-    std::vector<TreeNode> tree; /* level order first; renumbered at the end */
-    struct Open { int tree_id; };
-    std::vector<Open> open;
-    std::vector<LevelNode> lvl;
-    tree.push_back(TreeNode{{0, 0, 0, 0, 0, 0}, 0, n, -1, -1, 0});
-    open.push_back(Open{0});
-    std::vector<unsigned long long> keys;
-    std::vector<int32_t> h_perm;
-    const int B = 256, G = (n + B - 1) / B;
-    while (!open.empty()) {
-        const int m = (int)open.size();
-        lvl.assign((size_t)m, LevelNode{});
-        int largest = 0;
-        for (int q = 0; q < m; q++) {
-            const TreeNode &t = tree[(size_t)open[(size_t)q].tree_id];
-            lvl[(size_t)q].debut = t.debut; lvl[(size_t)q].fin = t.fin; lvl[(size_t)q].lead = -1;
-            if (t.fin - t.debut > largest) largest = t.fin - t.debut;
-        }
-        HIPCHK(c, hipMemcpyAsync(d_nd, lvl.data(), (size_t)m * sizeof(LevelNode), hipMemcpyHostToDevice, c->stream));
+    int m = 1, largest = n, tree_count = 1;
+    while (m > 0) {
+        const int Gm = (m + B - 1) / B;
+        HIPCHK(c, hipMemsetAsync(d_info, 0, sizeof(LevelInfo), c->stream));
+        hipLaunchKernelGGL(k_level_init, dim3(Gm), dim3(B), 0, c->stream, d_open, m, d_T, d_nd, d_keys, d_zfirst);
         hipLaunchKernelGGL(k_node_of, dim3(G), dim3(B), 0, c->stream, d_nd, m, n, d_node_of);
-        hipLaunchKernelGGL(k_box_init, dim3((m * 6 + B - 1) / B), dim3(B), 0, c->stream, d_keys, m);
         hipLaunchKernelGGL(k_box, dim3(G), dim3(B), 0, c->stream, d_verts, d_tri, d_perm, d_node_of, n, d_keys);
-        keys.resize((size_t)m * 6);
-        HIPCHK(c, hipMemcpyAsync(keys.data(), d_keys, (size_t)m * 48, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        bool need_perm = false;
-        for (int q = 0; q < m; q++) {
-            TreeNode &t = tree[(size_t)open[(size_t)q].tree_id];
-            bool zero = false;
-            for (int a = 0; a < 6; a++) { t.box[a] = value_of(keys[(size_t)q * 6 + a]); zero = zero || t.box[a] == 0.0; }
-            if (zero) need_perm = true;
-        }
-        if (need_perm) { /* the sign of a zero minimum or maximum depends on the order of the comparisons: redo those boxes as the reference does */
-            h_perm.resize((size_t)n);
-            HIPCHK(c, hipMemcpy(h_perm.data(), d_perm, (size_t)n * 4, hipMemcpyDeviceToHost));
-            for (int q = 0; q < m; q++) {
-                TreeNode &t = tree[(size_t)open[(size_t)q].tree_id];
-                bool zero = false;
-                for (int a = 0; a < 6; a++) zero = zero || t.box[a] == 0.0;
-                if (!zero) continue;
-                for (int a = 0; a < 3; a++) { t.box[a] = 1E9; t.box[3 + a] = -1E9; }
-                for (int i = t.debut; i < t.fin; i++)
-                    for (int a = 0; a < 3; a++)
-                        for (int v = 0; v < 3; v++) {
-                            const double x = verts[(size_t)tri_vtx[3 * (size_t)h_perm[(size_t)i] + v] * 3 + a];
-                            if (x < t.box[a]) t.box[a] = x;         /* std::min(a, b): b if b < a */
-                            if (t.box[3 + a] < x) t.box[3 + a] = x; /* std::max(a, b): b if a < b */
-                        }
-            }
-        }
-        for (int q = 0; q < m; q++) { /* :250-267 */
-            const TreeNode &t = tree[(size_t)open[(size_t)q].tree_id];
-            const double dx = t.box[3] - t.box[0], dy = t.box[4] - t.box[1], dz = t.box[5] - t.box[2];
-            int dim;
-            if (dx >= dy && dx >= dz) dim = 0;
-            else if (dy >= dx && dy >= dz) dim = 1;
-            else dim = 2;
-            lvl[(size_t)q].dim = dim;
-            lvl[(size_t)q].milieu = (t.box[dim] + t.box[3 + dim]) * 0.5;
-        }
-        HIPCHK(c, hipMemcpyAsync(d_nd, lvl.data(), (size_t)m * sizeof(LevelNode), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_zero_first, dim3(G), dim3(B), 0, c->stream, d_verts, d_tri, d_perm, d_node_of, n, d_keys, d_zfirst);
+        hipLaunchKernelGGL(k_axis, dim3(Gm), dim3(B), 0, c->stream, d_open, m, d_keys, d_zfirst, d_T, d_nd);
         hipLaunchKernelGGL(k_flags, dim3(G), dim3(B), 0, c->stream, d_verts, d_tri, d_perm, d_node_of, d_nd, n, d_flag);
         if (rocprim::exclusive_scan(d_tmp, tmp_bytes, d_flag, d_scan, 0, (size_t)n, rocprim::plus<int32_t>(), c->stream) != hipSuccess)
             return fail(c, RT_E_DEVICE, "rt_build_bvh: prefix sum failed");
@@ -306,36 +364,30 @@ extern "C" int rt_build_bvh(rt_ctx *c, const double *verts, int64_t nv, const in
         int rounds = 1;
         while ((1 << rounds) < largest + 1) rounds++;
         for (int r = 0; r < rounds + 1; r++) hipLaunchKernelGGL(k_jump, dim3(G), dim3(B), 0, c->stream, d_node_of, d_nd, n, d_V);
-        HIPCHK(c, hipMemsetAsync(d_unres, 0, 4, c->stream));
-        hipLaunchKernelGGL(k_back, dim3(G), dim3(B), 0, c->stream, d_node_of, d_nd, n, d_V, d_perm2, d_unres);
+        hipLaunchKernelGGL(k_back, dim3(G), dim3(B), 0, c->stream, d_node_of, d_nd, n, d_V, d_perm2, &d_info->unresolved);
+        hipLaunchKernelGGL(k_split_flags, dim3(Gm), dim3(B), 0, c->stream, d_nd, m, d_sflag);
+        if (rocprim::exclusive_scan(d_tmp, tmp_bytes, d_sflag, d_srank, 0, (size_t)m, rocprim::plus<int32_t>(), c->stream) != hipSuccess)
+            return fail(c, RT_E_DEVICE, "rt_build_bvh: prefix sum failed");
+        hipLaunchKernelGGL(k_split_apply, dim3(Gm), dim3(B), 0, c->stream, d_nd, m, d_sflag, d_srank, d_open, tree_count, d_T, d_open2, d_info);
         HIPCHK(c, hipGetLastError());
-        int unres = 0;
-        HIPCHK(c, hipMemcpyAsync(lvl.data(), d_nd, (size_t)m * sizeof(LevelNode), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(&unres, d_unres, 4, hipMemcpyDeviceToHost, c->stream));
+        LevelInfo info;
+        HIPCHK(c, hipMemcpyAsync(&info, d_info, sizeof info, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (unres) return fail(c, RT_E_DEVICE, "rt_build_bvh: internal error (unresolved queue entry)");
+        if (info.unresolved) return fail(c, RT_E_DEVICE, "rt_build_bvh: internal error (unresolved queue entry)");
         std::swap(d_perm, d_perm2);
-        std::vector<Open> next;
-        for (int q = 0; q < m; q++) { /* :283 */
-            const int id = open[(size_t)q].tree_id;
-            const int debut = tree[(size_t)id].debut, fin = tree[(size_t)id].fin, pivot = debut + lvl[(size_t)q].n_s;
-            if (pivot == debut || pivot == fin || fin - debut < 5) continue;
-            const int l = (int)tree.size();
-            tree.push_back(TreeNode{{0, 0, 0, 0, 0, 0}, debut, pivot, -1, -1, tree[(size_t)id].depth + 1});
-            tree.push_back(TreeNode{{0, 0, 0, 0, 0, 0}, pivot, fin, -1, -1, tree[(size_t)id].depth + 1});
-            tree[(size_t)id].fg = l;
-            tree[(size_t)id].fd = l + 1;
-            next.push_back(Open{l});
-            next.push_back(Open{l + 1});
-        }
-        open.swap(next);
+        std::swap(d_open, d_open2);
+        tree_count += info.m_next;
+        m = info.m_next;
+        largest = info.largest_next;
     }
-    if ((int64_t)tree.size() > node_cap) return fail(c, RT_E_INVALID, "rt_build_bvh: %zu nodes do not fit the caller's %lld", tree.size(), (long long)node_cap);
+    if ((int64_t)tree_count > node_cap) return fail(c, RT_E_INVALID, "rt_build_bvh: %d nodes do not fit the caller's %lld", tree_count, (long long)node_cap);
     HIPCHK(c, hipMemcpy(order, d_perm, (size_t)n * 4, hipMemcpyDeviceToHost));
+    std::unique_ptr<rt_build_node[]> tree(new rt_build_node[(size_t)tree_count]); /* level order; renumbered below */
+    HIPCHK(c, hipMemcpy(tree.get(), d_T, (size_t)tree_count * sizeof(rt_build_node), hipMemcpyDeviceToHost));
     /* the numbering of the reference's recursion: a node's two children get the next two numbers when it is split, and the
      * left subtree is completed before the right one */
     {
-        std::vector<int> newid(tree.size(), -1), stack;
+        std::vector<int> newid((size_t)tree_count, -1), stack;
         int count = 1;
         newid[0] = 0;
         stack.push_back(0);
@@ -348,15 +400,14 @@ extern "C" int rt_build_bvh(rt_ctx *c, const double *verts, int64_t nv, const in
             stack.push_back(tree[(size_t)id].fd);
             stack.push_back(tree[(size_t)id].fg);
         }
-        for (size_t id = 0; id < tree.size(); id++) {
-            const TreeNode &t = tree[id];
-            rt_build_node &o = nodes[(size_t)newid[id]];
-            for (int a = 0; a < 6; a++) o.box[a] = t.box[a];
-            o.debut = t.debut; o.fin = t.fin; o.depth = t.depth; o.pad = 0;
+        for (int id = 0; id < tree_count; id++) {
+            const rt_build_node &t = tree[(size_t)id];
+            rt_build_node &o = nodes[(size_t)newid[(size_t)id]];
+            o = t;
             o.fg = t.fg >= 0 ? newid[(size_t)t.fg] : -1;
             o.fd = t.fd >= 0 ? newid[(size_t)t.fd] : -1;
         }
     }
-    *n_nodes_out = (int64_t)tree.size();
+    *n_nodes_out = (int64_t)tree_count;
     return RT_OK;
 }
