@@ -78,29 +78,25 @@ __global__ void k_box(const double *verts, const int32_t *tri_vtx, const int32_t
             }
         }
     }
-    /* one atomic per wave and value where the whole wave sits in one node (the upper levels), else one per lane */
-    const int first = __builtin_amdgcn_readfirstlane(node);
-    const bool uniform = __ballot(node != first) == 0ull;
-    if (uniform) {
-        if (first < 0) return;
+    /* The positions of a node are contiguous, so the lanes of a wave fall into runs of equal node: a segmented
+     * reduction over the wave (combine with lane + 1, 2, 4 ... while it is in the same node) leaves every run's result
+     * in its first lane, and only those lanes touch memory. */
+    const int lane = (int)(threadIdx.x & 63);
+    for (int off = 1; off < 64; off <<= 1) {
+        const int other = __shfl_down(node, off, 64);
+        const bool same = (lane + off < 64) && other == node;
         for (int a = 0; a < 3; a++) {
-            for (int off = 32; off > 0; off >>= 1) {
-                const unsigned long long l2 = __shfl_xor(lo[a], off, 64), h2 = __shfl_xor(hi[a], off, 64);
-                if (l2 < lo[a]) lo[a] = l2;
-                if (h2 > hi[a]) hi[a] = h2;
-            }
+            const unsigned long long l2 = __shfl_down(lo[a], off, 64), h2 = __shfl_down(hi[a], off, 64);
+            if (same && l2 < lo[a]) lo[a] = l2;
+            if (same && h2 > hi[a]) hi[a] = h2;
         }
-        if ((threadIdx.x & 63) == 0)
-            for (int a = 0; a < 3; a++) {
-                atomicMin(keys + (size_t)first * 6 + a, lo[a]);
-                atomicMax(keys + (size_t)first * 6 + 3 + a, hi[a]);
-            }
-    } else if (node >= 0) {
+    }
+    const int before = __shfl_up(node, 1, 64);
+    if (node >= 0 && (lane == 0 || before != node))
         for (int a = 0; a < 3; a++) {
             atomicMin(keys + (size_t)node * 6 + a, lo[a]);
             atomicMax(keys + (size_t)node * 6 + 3 + a, hi[a]);
         }
-    }
 }
 
 /* S = "the triangle's centre along the node's axis lies below the middle" (:271-272); 0 outside the open nodes */
