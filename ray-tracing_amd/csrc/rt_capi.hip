@@ -327,8 +327,12 @@ static int32_t ext_split(const rt_tri *tris, int32_t first, int32_t n, std::vect
     return best;
 }
 
+#ifndef RT_SPHERE_LEAF
+#define RT_SPHERE_LEAF 1 /* spheres per leaf of the sphere tree. Measured on 1006 spheres (Mpaths/s): 1: 86, 2: 80, 4: 70, 8: 58, 16: 45 -
+                            the exact FP64 tests cost more than the extra nodes of a deeper tree */
+#endif
 /* The tree over a long sphere list (SphNode in rt_device.hip.h): median cuts of the centres along the widest axis down to
- * leaves of two spheres, nodes in depth-first order with skip links, spheres re-ordered into leaf order. `reach` is how
+ * leaves of RT_SPHERE_LEAF spheres, nodes in depth-first order with skip links, spheres re-ordered into leaf order. `reach` is how
  * far from the coordinate origin a ray may start for the margin of the boxes to hold: a hundred thousand times the
  * smallest radius, less the largest centre coordinate. (Sphere::intersect accepts delta = b^2 - 4c >= 0 as computed; its
  * rounding error is below 64 * 2^-53 |C - O|^2, so an accepted ray passes the centre within R sqrt(1 + 16 * 2^-53 |C - O|^2 / R^2)
@@ -380,7 +384,7 @@ static bool build_sphere_tree(const rt_sphere *sph, int n, std::vector<rt_sphere
             for (int a = 0; a < 6; a++) boxes_out.push_back((double)nd.box[a]);
             f.node = (int)nodes.size();
             nodes.push_back(nd);
-            if (f.count <= 2) {
+            if (f.count <= RT_SPHERE_LEAF) {
                 nodes[(size_t)f.node].first = f.first;
                 nodes[(size_t)f.node].count = f.count;
                 nodes[(size_t)f.node].skip = f.node + 1;

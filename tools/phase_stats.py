@@ -6,7 +6,10 @@ import numpy as np
 rta = importlib.import_module("ray-tracing_amd"); scenes = importlib.import_module("ray-tracing_amd.scenes")
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-s, cam, fl, meta = scenes.battle(W=W)
+if len(sys.argv) > 3 and sys.argv[3] == "stress":  # cfg5-like: 1 M triangles + 1000 spheres
+    s, cam, fl = scenes.stress(W=W, n_tris=1_000_000, n_spheres=1000)
+else:
+    s, cam, fl, meta = scenes.battle(W=W)
 r = rta.Renderer(0); r.upload(s); r.accum_clear(W, W); r.reset_counters()
 r.render(cam, rta.make_params(W, W, spp, flags=fl | rta.RT_F_COUNTERS)); r.sync()
 c = r.counters(); d = (C.c_uint64 * 20)(); rta.lib.rt_debug_stats(r._h, d)
