@@ -332,13 +332,15 @@ static int32_t ext_split(const rt_tri *tris, int32_t first, int32_t n, std::vect
                             the exact FP64 tests cost more than the extra nodes of a deeper tree */
 #endif
 /* The tree over a long sphere list (SphNode in rt_device.hip.h): median cuts of the centres along the widest axis down to
- * leaves of RT_SPHERE_LEAF spheres, nodes in depth-first order with skip links, spheres re-ordered into leaf order. `reach` is how
+ * leaves of RT_SPHERE_LEAF spheres, nodes in depth-first order with skip links - eight such orders, one per sign pattern
+ * of a ray's direction, concatenated -, spheres re-ordered into leaf order. `reach` is how
  * far from the coordinate origin a ray may start for the margin of the boxes to hold: a hundred thousand times the
  * smallest radius, less the largest centre coordinate. (Sphere::intersect accepts delta = b^2 - 4c >= 0 as computed; its
  * rounding error is below 64 * 2^-53 |C - O|^2, so an accepted ray passes the centre within R sqrt(1 + 16 * 2^-53 |C - O|^2 / R^2)
  * <= R (1 + 3e-5) when |C - O| <= sqrt(3) * 1e5 R: inside the boxes' margin of R / 1000.) Returns false for a non-finite sphere. */
-static bool build_sphere_tree(const rt_sphere *sph, int n, std::vector<rt_sphere> &sorted, std::vector<SphNode> &nodes, std::vector<double> &boxes_out,
-                              double *reach) {
+static bool build_sphere_tree(const rt_sphere *sph, int n_all, std::vector<rt_sphere> &sorted, std::vector<SphNode> &nodes, std::vector<double> &boxes_out,
+                              double *reach, int *n_big_out) {
+    const int n = n_all;
     std::vector<int> idx((size_t)n);
     double rmin = HUGE_VAL, omax = 0;
     for (int i = 0; i < n; i++) {
@@ -355,16 +357,33 @@ static bool build_sphere_tree(const rt_sphere *sph, int n, std::vector<rt_sphere
         const double m = sph[i].R * 1.001 + 1e-300;
         for (int a = 0; a < 3; a++) { b[a] = sph[i].O[a] - m; b[3 + a] = sph[i].O[a] + m; }
     };
-    /* depth-first emission with an explicit stack: a node is written when it is reached, its skip when its subtree is complete */
-    struct Frame { int node, first, count, stage; };
-    std::vector<Frame> st;
-    st.push_back(Frame{-1, 0, n, 0});
-    while (!st.empty()) {
-        Frame &f = st.back();
-        if (f.stage == 0) {
+    /* Spheres much larger than the rest (the walls of the reference's scenes are spheres of radius ~1000) would blow up
+     * every box above them: they stay out of the tree, at the front of the list, and every ray tests them first - which
+     * also gives the walk a closest hit to prune with. */
+    int n_big = 0;
+    {
+        std::vector<double> radii((size_t)n);
+        for (int i = 0; i < n; i++) radii[(size_t)i] = sph[i].R;
+        std::nth_element(radii.begin(), radii.begin() + n / 2, radii.end());
+        const double big = 4 * radii[(size_t)(n / 2)];
+        n_big = (int)(std::stable_partition(idx.begin(), idx.end(), [&](int i) { return sph[i].R > big; }) - idx.begin());
+        if (n_big > RT_LDS_SPHERES_MAX || n_big == n) n_big = 0; /* no such outliers (or only such): everything goes into the tree */
+    }
+    *n_big_out = n_big;
+    /* the tree itself: median cuts, children by index */
+    struct BNode { float box[6]; int left, right, axis, first, count; };
+    std::vector<BNode> tree;
+    {
+        struct Job { int node, first, count; };
+        std::vector<Job> jobs;
+        tree.push_back(BNode{});
+        jobs.push_back(Job{0, n_big, n - n_big});
+        while (!jobs.empty()) {
+            const Job jb = jobs.back();
+            jobs.pop_back();
             double box[6] = {HUGE_VAL, HUGE_VAL, HUGE_VAL, -HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
             double clo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, chi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
-            for (int k = f.first; k < f.first + f.count; k++) {
+            for (int k = jb.first; k < jb.first + jb.count; k++) {
                 double b[6];
                 sphere_box(idx[(size_t)k], b);
                 for (int a = 0; a < 3; a++) {
@@ -375,42 +394,76 @@ static bool build_sphere_tree(const rt_sphere *sph, int n, std::vector<rt_sphere
                     if (ctr > chi[a]) chi[a] = ctr;
                 }
             }
-            SphNode nd;
+            BNode nd;
             memset(&nd, 0, sizeof nd);
             for (int a = 0; a < 3; a++) {
                 nd.box[a] = nextafterf((float)box[a], -HUGE_VALF);
                 nd.box[3 + a] = nextafterf((float)box[3 + a], HUGE_VALF);
             }
             for (int a = 0; a < 6; a++) boxes_out.push_back((double)nd.box[a]);
-            f.node = (int)nodes.size();
-            nodes.push_back(nd);
-            if (f.count <= RT_SPHERE_LEAF) {
-                nodes[(size_t)f.node].first = f.first;
-                nodes[(size_t)f.node].count = f.count;
-                nodes[(size_t)f.node].skip = f.node + 1;
-                st.pop_back();
+            nd.left = nd.right = -1;
+            nd.first = jb.first;
+            nd.count = jb.count;
+            if (jb.count > RT_SPHERE_LEAF) {
+                int axis = 0;
+                for (int a = 1; a < 3; a++)
+                    if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
+                const int half = jb.count / 2;
+                std::nth_element(idx.begin() + jb.first, idx.begin() + jb.first + half, idx.begin() + jb.first + jb.count,
+                                 [&](int x, int y) { return sph[x].O[axis] < sph[y].O[axis] || (sph[x].O[axis] == sph[y].O[axis] && x < y); });
+                nd.axis = axis;
+                nd.left = (int)tree.size();
+                nd.right = nd.left + 1;
+                tree.push_back(BNode{});
+                tree.push_back(BNode{});
+                jobs.push_back(Job{nd.left, jb.first, half});               /* lower centres */
+                jobs.push_back(Job{nd.right, jb.first + half, jb.count - half}); /* upper centres */
+            }
+            tree[(size_t)jb.node] = nd;
+        }
+    }
+    /* Eight depth-first layouts, one per sign pattern of a ray's direction: in layout o the child that a ray of that
+     * pattern reaches first (the lower one along the cut's axis if the ray runs up that axis) comes first, so the walk
+     * meets near spheres before far ones and the closest hit so far cuts off what lies behind it. */
+    const int per = (int)tree.size();
+    nodes.assign((size_t)per * 8, SphNode{});
+    for (int o = 0; o < 8; o++) {
+        struct Frame { int bnode, out, stage; };
+        std::vector<Frame> st;
+        int emitted = 0;
+        st.push_back(Frame{0, -1, 0});
+        while (!st.empty()) {
+            Frame &f = st.back();
+            const BNode &bn = tree[(size_t)f.bnode];
+            if (f.stage == 0) {
+                f.out = emitted++;
+                SphNode &nd = nodes[(size_t)o * per + f.out];
+                for (int a = 0; a < 6; a++) nd.box[a] = bn.box[a];
+                if (bn.left < 0) {
+                    nd.first = bn.first;
+                    nd.count = bn.count;
+                    nd.skip = f.out + 1;
+                    st.pop_back();
+                    continue;
+                }
+                nd.first = 0;
+                nd.count = 0;
+                f.stage = 1;
+                const bool down = (o >> bn.axis) & 1; /* the ray runs down the axis: upper child first */
+                const Frame nxt{down ? bn.right : bn.left, -1, 0};
+                st.push_back(nxt); /* invalidates f */
                 continue;
             }
-            int axis = 0;
-            for (int a = 1; a < 3; a++)
-                if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
-            const int half = f.count / 2;
-            std::nth_element(idx.begin() + f.first, idx.begin() + f.first + half, idx.begin() + f.first + f.count,
-                             [&](int x, int y) { return sph[x].O[axis] < sph[y].O[axis] || (sph[x].O[axis] == sph[y].O[axis] && x < y); });
-            f.stage = 1;
-            const Frame left{-1, f.first, half, 0};
-            st.push_back(left); /* invalidates f */
-            continue;
+            if (f.stage == 1) {
+                f.stage = 2;
+                const bool down = (o >> bn.axis) & 1;
+                const Frame nxt{down ? bn.left : bn.right, -1, 0};
+                st.push_back(nxt);
+                continue;
+            }
+            nodes[(size_t)o * per + f.out].skip = emitted; /* the node after this subtree */
+            st.pop_back();
         }
-        if (f.stage == 1) {
-            f.stage = 2;
-            const int half = f.count / 2;
-            const Frame right{-1, f.first + half, f.count - half, 0};
-            st.push_back(right);
-            continue;
-        }
-        nodes[(size_t)f.node].skip = (int)nodes.size(); /* the node after this subtree */
-        st.pop_back();
     }
     sorted.resize((size_t)n);
     for (int i = 0; i < n; i++) sorted[(size_t)i] = sph[idx[(size_t)i]];
@@ -506,12 +559,14 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
         std::vector<rt_sphere> sorted;
         std::vector<SphNode> nodes;
         double reach = 0;
-        if (!build_sphere_tree(s->spheres, s->n_spheres, sorted, nodes, sphere_boxes, &reach))
+        int n_big = 0;
+        if (!build_sphere_tree(s->spheres, s->n_spheres, sorted, nodes, sphere_boxes, &reach, &n_big))
             return fail(c, RT_E_INVALID, "rt_upload_scene: a sphere has a non-finite centre or radius");
         if ((rc = upload_array(c, sorted.data(), sorted.size(), &d.spheres))) return rc;
         if ((rc = upload_array(c, nodes.data(), nodes.size(), &d.sph_nodes))) return rc;
-        d.n_sph_nodes = (int32_t)nodes.size();
+        d.n_sph_nodes = (int32_t)(nodes.size() / 8); /* per layout */
         d.sph_reach = reach;
+        d.n_sph_big = n_big;
         for (size_t k = 0; k + 6 <= sphere_boxes.size(); k += 6) widen(&sphere_boxes[k]);
         HIPCHK(c, hipStreamSynchronize(c->stream)); /* the staging vectors go out of scope */
     } else if ((rc = upload_array(c, s->spheres, (size_t)s->n_spheres, &d.spheres))) {

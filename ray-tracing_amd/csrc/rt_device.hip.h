@@ -70,8 +70,8 @@ static_assert(RT_NODE_SOFT_MIN > RT_FEED_MARGIN + RT_WAVE && RT_NODE_SOFT_MIN <=
 static_assert(RT_LEAF_CAP >= 5 * RT_WAVE, "a node step adds up to 256 leaf items (filter tree: four children) and runs only when 256 slots are free; a fed mesh adds up to 128 on top of 64");
 #define RT_PHANTOM_BASE (1 << 30)  /* best_pos values from here on: "mesh (value - base) reports a hit without a triangle" */
 
-/* One node of the sphere tree, 48 bytes. Nodes lie in depth-first order: a ray that may touch `box` goes on with the next
- * node, any other with node `skip`; a leaf (count > 0) holds spheres first .. first + count - 1 and its skip is the next
+/* One node of the sphere tree, 48 bytes. Nodes lie in depth-first order (eight orders, one per sign pattern of the ray's
+ * direction, n_sph_nodes each): a ray that may touch `box` goes on with the next node, any other with node `skip`; a leaf (count > 0) holds spheres first .. first + count - 1 and its skip is the next
  * node. The boxes are the spheres' boxes enlarged by a thousandth of the radius and rounded outwards to float: Sphere::
  * intersect (raytracer.cpp:883-918) can report a hit for a ray that passes a sphere by a rounding error, which stays
  * inside that margin as long as the ray starts within a hundred thousand radii (DScene::sph_reach). */
@@ -143,7 +143,8 @@ struct DScene {
     /* Sphere lists too long for LDS: a tree over the spheres' boxes (SphNode, depth-first order with skip links) that a lane
      * walks without a stack; `spheres` is then in the tree's leaf order. Null for short lists. */
     const struct SphNode *sph_nodes;
-    int32_t n_sph_nodes, pad_sph;
+    int32_t n_sph_nodes; /* per direction layout */
+    int32_t n_sph_big;   /* spheres at the front of the list that are not in the tree (far larger than the rest): tested by every ray */
     double sph_reach; /* rays whose origin lies farther than this from the coordinate origin (any axis) test every sphere instead */
     double I;
     double L[3];
@@ -490,10 +491,14 @@ __device__ __forceinline__ void ray_begin(const DScene &sc, WaveLDS *w, const rt
         kf.iux = (float)k.iu.x; kf.iuy = (float)k.iu.y; kf.iuz = (float)k.iu.z;
         kf.ncx = (float)k.nc.x; kf.ncy = (float)k.nc.y; kf.ncz = (float)k.nc.z;
         kf.tol = (float)(k.tol * RT_TOLF_SCALE);
+        const int n_big = uni(sc.n_sph_big);
+        for (int s = 0; s < n_big; s++) sphere_test(sph, s, C, u, h);
         const int n_nodes = sc.n_sph_nodes;
+        /* the layout for this ray's direction: near children first */
+        const SphNode *const layout = sc.sph_nodes + (size_t)((u.x < 0 ? 1 : 0) | (u.y < 0 ? 2 : 0) | (u.z < 0 ? 4 : 0)) * (size_t)n_nodes;
         int i = 0;
         for (int guard = 0; i < n_nodes && guard <= n_nodes; guard++) {
-            const SphNode nd = sc.sph_nodes[i];
+            const SphNode nd = layout[i];
             bool hit, unsure;
             float tlo;
             box_fast_f(nd.box[0], nd.box[1], nd.box[2], nd.box[3], nd.box[4], nd.box[5], kf, hit, unsure, tlo);
