@@ -59,7 +59,22 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_kernel(DScene
      * copy in LDS where it is needed */
     if (threadIdx.x == 0) { w->sc = sc; w->ra = ra; }
     wave_sync();
-    render_persistent<CNT>(sc, w->sc, w, sph, roots, w->ra, k0, nk, accum, next_slot, n_slots, cnt);
+    render_persistent<CNT, false>(sc, w->sc, w, sph, roots, w->ra, k0, nk, accum, next_slot, n_slots, cnt);
+    if (CNT) flush_counters(cnt, counters);
+}
+
+/* the same for scenes whose sphere list is too long for LDS: with the walk through the sphere tree compiled in */
+template <bool CNT>
+__global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_spheres_kernel(DScene sc, RenderArgs ra, int k0, int nk, double *accum,
+                                                                     rt_counters *counters, int *next_slot, int n_slots) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const rt_sphere *sph;
+    const RootRec *roots;
+    WaveLDS *w = wave_setup(sc, lds_raw, &sph, &roots);
+    Cnt cnt = {};
+    if (threadIdx.x == 0) { w->sc = sc; w->ra = ra; }
+    wave_sync();
+    render_persistent<CNT, true>(sc, w->sc, w, sph, roots, w->ra, k0, nk, accum, next_slot, n_slots, cnt);
     if (CNT) flush_counters(cnt, counters);
 }
 
@@ -73,7 +88,7 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_sample_kernel(DScene sc, RenderAr
     const bool live = q < n;
     Cnt cnt = {};
     const int i = live ? ijk[3 * q] : 0, j = live ? ijk[3 * q + 1] : 0, k = live ? ijk[3 * q + 2] : 0;
-    V3 a = trace_pixel<false>(sc, sc, w, sph, roots, ra, live, i, j, k, 1, cnt);
+    V3 a = trace_pixel<false, true>(sc, sc, w, sph, roots, ra, live, i, j, k, 1, cnt);
     if (live) {
         out[3 * q] = a.x;
         out[3 * q + 1] = a.y;
@@ -96,7 +111,7 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_intersect_kernel(DScene sc, const
     Cnt cnt = {};
     HitRec h2;
     const RayQ qa = RayQ{live, C, u, 1E10, false}, qb = RayQ{false, C, u, 1E10, false};
-    scene_closest_wave<false>(sc, sc, w, sph, roots, qa, qb, prune != 0, h, h2, cnt);
+    scene_closest_wave<false, true>(sc, sc, w, sph, roots, qa, qb, prune != 0, h, h2, cnt);
     const bool ok = h.obj != INT32_MAX;
     if (!live) return;
     obj_id[q] = ok ? h.obj : -1;
@@ -786,7 +801,11 @@ int rt_render(rt_ctx *c, const rt_camera *cam, const rt_params *p, double *accum
         for (int k = 0; k < p->spp; k += kSppPerLaunch) {
             const int nk = (p->spp - k < kSppPerLaunch) ? (p->spp - k) : kSppPerLaunch;
             HIPCHK(c, hipMemsetAsync(c->d_next_slot, 0, sizeof(int), c->stream));
-            if (p->flags & RT_F_COUNTERS)
+            if (c->sc.sph_nodes != nullptr && (p->flags & RT_F_COUNTERS))
+                hipLaunchKernelGGL(rt_render_spheres_kernel<true>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, accum, c->d_counters, c->d_next_slot, n_slots);
+            else if (c->sc.sph_nodes != nullptr)
+                hipLaunchKernelGGL(rt_render_spheres_kernel<false>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, accum, c->d_counters, c->d_next_slot, n_slots);
+            else if (p->flags & RT_F_COUNTERS)
                 hipLaunchKernelGGL(rt_render_kernel<true>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, accum, c->d_counters, c->d_next_slot, n_slots);
             else
                 hipLaunchKernelGGL(rt_render_kernel<false>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, accum, c->d_counters, c->d_next_slot, n_slots);

@@ -468,44 +468,89 @@ __device__ __forceinline__ void sphere_test(const rt_sphere *sph, int s, V3 C, V
     if (t < h.t || (t == h.t && oid < h.obj)) { h.t = t; h.obj = oid; h.prim = s; h.mesh = -1; }
 }
 
-/* Spheres for one ray and the ray's entry in the pool's tables. */
-template <bool CNT>
-__device__ __forceinline__ void ray_begin(const DScene &sc, WaveLDS *w, const rt_sphere *sph, int slot, const RayQ &q, bool prune, HitRec &h, Cnt &cnt) {
+__device__ __forceinline__ void hit_none(HitRec &h) {
     h.t = 1E10;
     h.obj = INT32_MAX;
     h.prim = -1;
     h.mesh = -1;
     h.group = 0;
     h.beta = h.gamma = 0;
+}
+/* the margins of the sphere tree's boxes hold for rays that start within DScene::sph_reach of the coordinate origin */
+__device__ __forceinline__ bool sphere_walk_ok(const DScene &sc, V3 C) { return fabs(C.x) < sc.sph_reach && fabs(C.y) < sc.sph_reach && fabs(C.z) < sc.sph_reach; }
+
+struct SphereWalk { /* one ray's walk through the sphere tree */
+    RayKf kf;
+    const SphNode *layout;
+    int i;
+};
+__device__ __forceinline__ void sphere_walk_begin(const DScene &sc, const RayQ &q, bool on, SphereWalk &sw) {
+    const RayK k = ray_constants(sc, q.C, q.u);
+    sw.kf.iux = (float)k.iu.x; sw.kf.iuy = (float)k.iu.y; sw.kf.iuz = (float)k.iu.z;
+    sw.kf.ncx = (float)k.nc.x; sw.kf.ncy = (float)k.nc.y; sw.kf.ncz = (float)k.nc.z;
+    sw.kf.tol = (float)(k.tol * RT_TOLF_SCALE);
+    /* the layout for this ray's direction: near children first */
+    sw.layout = sc.sph_nodes + (size_t)((q.u.x < 0 ? 1 : 0) | (q.u.y < 0 ? 2 : 0) | (q.u.z < 0 ? 4 : 0)) * (size_t)sc.n_sph_nodes;
+    sw.i = on ? 0 : sc.n_sph_nodes;
+}
+__device__ __forceinline__ void sphere_walk_step(const rt_sphere *sph, const RayQ &q, const SphNode &nd, SphereWalk &sw, HitRec &h) {
+    bool hit, unsure;
+    float tlo;
+    box_fast_f(nd.box[0], nd.box[1], nd.box[2], nd.box[3], nd.box[4], nd.box[5], sw.kf, hit, unsure, tlo);
+    const double bound = h.t < q.tmax ? h.t : q.tmax;
+    if (!(hit || unsure) || (double)tlo > bound) { sw.i = nd.skip; return; } /* certainly missed, or wholly behind what is known */
+    for (int s = nd.first; s < nd.first + nd.count; s++) sphere_test(sph, s, q.C, q.u, h);
+    sw.i++;
+}
+
+/* Long sphere lists, both rays of a lane at once (their walks are chains of dependent loads: two chains in flight
+ * take the time of the longer one). Only the spheres whose (enlarged) boxes a ray may touch, and that can still
+ * matter - nearer than the closest hit so far and than tmax -, get the exact test; the winner is the same, because
+ * the choice among tested spheres (smallest t, then smallest objectId) does not depend on their order. Rays outside
+ * the tree's reach are left to ray_begin (done_* stays false). */
+__device__ __forceinline__ void spheres_walk2(const DScene &sc, const rt_sphere *sph, const RayQ &qa, const RayQ &qb, HitRec &ha, HitRec &hb, bool &done_a,
+                                              bool &done_b) {
+    hit_none(ha);
+    hit_none(hb);
+    done_a = qa.active && sphere_walk_ok(sc, qa.C);
+    done_b = qb.active && sphere_walk_ok(sc, qb.C);
+    if (__ballot(done_a || done_b) == 0ull) return;
+    const int n_big = uni(sc.n_sph_big), n_nodes = uni(sc.n_sph_nodes);
+    for (int s = 0; s < n_big; s++) {
+        if (done_a) sphere_test(sph, s, qa.C, qa.u, ha);
+        if (done_b) sphere_test(sph, s, qb.C, qb.u, hb);
+    }
+    SphereWalk wa, wb;
+    sphere_walk_begin(sc, qa, done_a, wa);
+    sphere_walk_begin(sc, qb, done_b, wb);
+    for (int guard = 0; (wa.i < n_nodes || wb.i < n_nodes) && guard <= 2 * n_nodes; guard++) {
+        const bool go_a = wa.i < n_nodes, go_b = wb.i < n_nodes;
+        const SphNode na = wa.layout[go_a ? wa.i : 0], nb = wb.layout[go_b ? wb.i : 0];
+        if (go_a) sphere_walk_step(sph, qa, na, wa, ha);
+        if (go_b) sphere_walk_step(sph, qb, nb, wb, hb);
+    }
+}
+
+/* Spheres for one ray and the ray's entry in the pool's tables. */
+template <bool CNT, bool SPH>
+__device__ __forceinline__ void ray_begin(const DScene &sc, WaveLDS *w, const rt_sphere *sph, int slot, const RayQ &q, bool prune, bool spheres_done,
+                                          HitRec &h, Cnt &cnt) {
+    if (!spheres_done) hit_none(h);
     if (!q.active) return;
     const V3 C = q.C, u = q.u;
     if (CNT) cnt.rays++;
     const int n_sph = uni(sc.n_spheres); /* wave-uniform also when read from LDS */
-    const bool walk = sc.sph_nodes != nullptr && prune && fabs(C.x) < sc.sph_reach && fabs(C.y) < sc.sph_reach && fabs(C.z) < sc.sph_reach;
-    if (sc.sph_nodes != nullptr && walk) {
-        /* Long sphere lists: only the spheres whose (enlarged) boxes the ray may touch, and that can still matter - nearer
-         * than the closest hit so far and than tmax -, get the test below; the winner is the same, because the choice
-         * among tested spheres (smallest t, then smallest objectId) does not depend on their order. */
-        const RayK k = ray_constants(sc, C, u);
-        RayKf kf;
-        kf.iux = (float)k.iu.x; kf.iuy = (float)k.iu.y; kf.iuz = (float)k.iu.z;
-        kf.ncx = (float)k.nc.x; kf.ncy = (float)k.nc.y; kf.ncz = (float)k.nc.z;
-        kf.tol = (float)(k.tol * RT_TOLF_SCALE);
-        const int n_big = uni(sc.n_sph_big);
+    if (spheres_done) {
+        /* spheres_walk2 has been here */
+    } else if (SPH && sc.sph_nodes != nullptr && prune && sphere_walk_ok(sc, C)) {
+        /* a single ray's walk (the probes; the render loop walks both rays of a lane together: spheres_walk2) */
+        const int n_big = uni(sc.n_sph_big), n_nodes = uni(sc.n_sph_nodes);
         for (int s = 0; s < n_big; s++) sphere_test(sph, s, C, u, h);
-        const int n_nodes = sc.n_sph_nodes;
-        /* the layout for this ray's direction: near children first */
-        const SphNode *const layout = sc.sph_nodes + (size_t)((u.x < 0 ? 1 : 0) | (u.y < 0 ? 2 : 0) | (u.z < 0 ? 4 : 0)) * (size_t)n_nodes;
-        int i = 0;
-        for (int guard = 0; i < n_nodes && guard <= n_nodes; guard++) {
-            const SphNode nd = layout[i];
-            bool hit, unsure;
-            float tlo;
-            box_fast_f(nd.box[0], nd.box[1], nd.box[2], nd.box[3], nd.box[4], nd.box[5], kf, hit, unsure, tlo);
-            const double bound = h.t < q.tmax ? h.t : q.tmax;
-            if (!(hit || unsure) || (double)tlo > bound) { i = nd.skip; continue; } /* certainly missed, or wholly behind what is known */
-            for (int s = nd.first; s < nd.first + nd.count; s++) sphere_test(sph, s, C, u, h);
-            i++;
+        SphereWalk sw;
+        sphere_walk_begin(sc, q, true, sw);
+        for (int guard = 0; sw.i < n_nodes && guard <= n_nodes; guard++) {
+            const SphNode nd = sw.layout[sw.i];
+            sphere_walk_step(sph, q, nd, sw, h);
         }
     } else {
         for (int s = 0; s < n_sph; s++) sphere_test(sph, s, C, u, h);
@@ -692,7 +737,9 @@ __device__ __forceinline__ void wide_children(const DScene &sc, WaveLDS *w, int 
 
 /* Scene::intersect, raytracer.cpp:930-951, for up to two rays per lane (slots lane and 64 + lane). Called by all
  * 64 lanes together; active rays get their closest hit. */
-template <bool CNT>
+/* SPH: compiled with the walk through the sphere tree (scenes with long sphere lists); without it the code for short
+ * lists is exactly what it was before the tree existed. */
+template <bool CNT, bool SPH>
 __device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScene &cold, WaveLDS *w, const rt_sphere *sph, const RootRec *roots, const RayQ &qa0, const RayQ &qb0,
                                                    bool prune, HitRec &ha, HitRec &hb, Cnt &cnt) {
     const int lane = lane_id();
@@ -710,8 +757,10 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScen
     HitRec kept_a = {}, kept_b = {};
     bool kept = false, redo_a = false, redo_b = false;
   for (;;) {
-    ray_begin<CNT>(cold, w, sph, lane, qa, prune, ha, cnt);
-    ray_begin<CNT>(cold, w, sph, RT_WAVE + lane, qb, prune, hb, cnt);
+    bool sa = false, sb = false;
+    if (SPH && cold.sph_nodes != nullptr && prune) spheres_walk2(cold, sph, qa, qb, ha, hb, sa, sb);
+    ray_begin<CNT, SPH>(cold, w, sph, lane, qa, prune, sa, ha, cnt);
+    ray_begin<CNT, SPH>(cold, w, sph, RT_WAVE + lane, qb, prune, sb, hb, cnt);
     if (CNT) { const uint64_t t = RT_STAMP(); cnt.cyc_roots += t - st0; st0 = t; } /* spheres and ray constants count with the roots */
     if (sc.n_meshes == 0) return;
     const NodeRec32 *const recs = sc.rec32;
@@ -1270,7 +1319,7 @@ __device__ __forceinline__ void path_advance(const DScene &sc, const rt_sphere *
 /* Single-kernel form: sum of the radiance of samples k0 .. k0+nk-1 of pixel (i, j), added in that
  * order (the k loop of raytracer.cpp:1464-1486). Called by all 64 lanes of the wave; lanes with
  * live == false only help in the pool. */
-template <bool CNT>
+template <bool CNT, bool SPH>
 __device__ __forceinline__ V3 trace_pixel(const DScene &sc, const DScene &cold, WaveLDS *w, const rt_sphere *sph, const RootRec *roots, const RenderArgs &ra, bool live, int i,
                                           int j, int k0, int nk, Cnt &cnt) {
     Path q;
@@ -1285,7 +1334,7 @@ __device__ __forceinline__ V3 trace_pixel(const DScene &sc, const DScene &cold, 
         HitRec h, hs;
         const RayQ qa = RayQ{!q.finished && q.segment, q.rC, q.ru, 1E10, false};
         const RayQ qb = RayQ{!q.finished && q.shadow, q.shC, q.shU, q.sh_limit, true};
-        scene_closest_wave<CNT>(sc, cold, w, sph, roots, qa, qb, !(ra.p.flags & RT_F_NO_PRUNE), h, hs, cnt);
+        scene_closest_wave<CNT, SPH>(sc, cold, w, sph, roots, qa, qb, !(ra.p.flags & RT_F_NO_PRUNE), h, hs, cnt);
         if (CNT) sp0 = RT_STAMP();
         if (!q.finished) path_advance<CNT>(cold, sph, ra, q, h.obj != INT32_MAX, h, hs.obj != INT32_MAX, hs, cnt);
         if (CNT) cnt.cyc_shade += RT_STAMP() - sp0;
@@ -1309,7 +1358,7 @@ __device__ __forceinline__ bool slot_pixel(const RenderArgs &ra, int64_t slot, i
  * per request; a lane keeps its pixel for all nk samples (added in order, raytracer.cpp:1464-1486), writes the
  * sum and takes the next free slot. Because lanes re-fill independently, the wave's pool stays full until the
  * whole frame runs out of pixels, instead of idling while the longest of 64 fixed pixels finishes. */
-template <bool CNT>
+template <bool CNT, bool SPH>
 __device__ __forceinline__ void render_persistent(const DScene &sc, const DScene &cold, WaveLDS *w, const rt_sphere *sph, const RootRec *roots,
                                                   const RenderArgs &ra, int k0, int nk, double *accum, int *next_slot, int n_slots,
                                                   Cnt &cnt) {
@@ -1360,7 +1409,7 @@ __device__ __forceinline__ void render_persistent(const DScene &sc, const DScene
         HitRec h, hs;
         const RayQ qa = RayQ{!q.finished && q.segment, q.rC, q.ru, 1E10, false};
         const RayQ qb = RayQ{!q.finished && q.shadow, q.shC, q.shU, q.sh_limit, true};
-        scene_closest_wave<CNT>(sc, cold, w, sph, roots, qa, qb, !(ra.p.flags & RT_F_NO_PRUNE), h, hs, cnt);
+        scene_closest_wave<CNT, SPH>(sc, cold, w, sph, roots, qa, qb, !(ra.p.flags & RT_F_NO_PRUNE), h, hs, cnt);
         if (CNT) sp0 = RT_STAMP();
         if (!q.finished) path_advance<CNT>(cold, sph, ra, q, h.obj != INT32_MAX, h, hs.obj != INT32_MAX, hs, cnt);
         if (CNT) cnt.cyc_shade += RT_STAMP() - sp0;
