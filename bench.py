@@ -172,7 +172,7 @@ def main():
         achieved_tflops = flops_per_path * paths_per_launch / avg_launch_s / 1e12
         roofline = {"bound": "valu_fp64", "achieved": round(achieved_tflops, 4), "peak": PEAK_FP64_VECTOR_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved_tflops / PEAK_FP64_VECTOR_TFLOPS, 5), "traffic": None,
-                    "kernel": "rt_render_kernel<false>", "avg_launch_ms": round(avg_launch_s * 1e3, 3), "launches": kernel_launches,
+                    "kernel": "rt_render_kernel<false, true>", "avg_launch_ms": round(avg_launch_s * 1e3, 3), "launches": kernel_launches,
                     "algorithmic_flops_per_path": round(flops_per_path, 1), "transcendentals_per_path": round(transc / c["paths"], 2),
                     "algorithmic_bytes_per_path": round(bytes_per_path, 1),
                     "hbm_side": {"achieved_GBs": round(bytes_per_path * paths_per_launch / avg_launch_s / 1e9, 2), "peak_GBs": PEAK_HBM_GBS,
@@ -188,7 +188,7 @@ def main():
         # gfx950 correction for 128-byte requests prescribes. Null when the summary is absent.
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", PROFILE_PREFIX + "mem2.json")))
-            kk = [k for k in pm if "rt_render_kernel<false>" in k][0]
+            kk = [k for k in pm if "rt_render_kernel<false, true>" in k][0]
             roofline["traffic"] = round(pm[kk]["FETCH_SIZE"] * 1024.0 * 2.0 / pm[kk]["dispatches"], 1)
             roofline["traffic_note"] = ("bytes per launch of 1024x1024x64 paths from profiles/%smem2.json (rocprofv3 --pmc FETCH_SIZE of "
                                         "`bench.py --steps 2 --warmup 1 --no-cpu-baseline`, 64 spp per launch), x2 gfx950 correction; "

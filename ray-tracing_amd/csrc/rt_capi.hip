@@ -47,7 +47,9 @@ __device__ __forceinline__ WaveLDS *wave_setup(const DScene &sc, unsigned char *
     return w;
 }
 
-template <bool CNT>
+/* CNT: with work counters. PLAIN: no mode flag of rt_params is set (what a production render uses): the other modes'
+ * code is left out. */
+template <bool CNT, bool PLAIN = false>
 __global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_kernel(DScene sc, RenderArgs ra, int k0, int nk, double *accum,
                                                              rt_counters *counters, int *next_slot, int n_slots) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -59,7 +61,7 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_kernel(DScene
      * copy in LDS where it is needed */
     if (threadIdx.x == 0) { w->sc = sc; w->ra = ra; }
     wave_sync();
-    render_persistent<CNT, false>(sc, w->sc, w, sph, roots, w->ra, k0, nk, accum, next_slot, n_slots, cnt);
+    render_persistent<CNT, false, PLAIN>(sc, w->sc, w, sph, roots, w->ra, k0, nk, accum, next_slot, n_slots, cnt);
     if (CNT) flush_counters(cnt, counters);
 }
 
@@ -74,7 +76,7 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_spheres_kerne
     Cnt cnt = {};
     if (threadIdx.x == 0) { w->sc = sc; w->ra = ra; }
     wave_sync();
-    render_persistent<CNT, true>(sc, w->sc, w, sph, roots, w->ra, k0, nk, accum, next_slot, n_slots, cnt);
+    render_persistent<CNT, true, false>(sc, w->sc, w, sph, roots, w->ra, k0, nk, accum, next_slot, n_slots, cnt);
     if (CNT) flush_counters(cnt, counters);
 }
 
@@ -805,6 +807,8 @@ int rt_render(rt_ctx *c, const rt_camera *cam, const rt_params *p, double *accum
                 hipLaunchKernelGGL(rt_render_spheres_kernel<true>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, accum, c->d_counters, c->d_next_slot, n_slots);
             else if (c->sc.sph_nodes != nullptr)
                 hipLaunchKernelGGL(rt_render_spheres_kernel<false>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, accum, c->d_counters, c->d_next_slot, n_slots);
+            else if (p->flags == 0)
+                hipLaunchKernelGGL((rt_render_kernel<false, true>), dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, accum, c->d_counters, c->d_next_slot, n_slots);
             else if (p->flags & RT_F_COUNTERS)
                 hipLaunchKernelGGL(rt_render_kernel<true>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, accum, c->d_counters, c->d_next_slot, n_slots);
             else

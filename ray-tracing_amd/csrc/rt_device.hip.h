@@ -1147,7 +1147,9 @@ __device__ __forceinline__ void path_begin(Path &q, int k0, bool live) {
 
 /* Start the next sample of pixel (i, j) if the previous one has ended: one iteration of the k loop
  * up to the getColor call, raytracer.cpp:1464-1483. */
-template <bool CNT>
+/* PLAIN (here and below): the caller knows that no mode flag is set (the estimator as the reference has it committed), so
+ * the code of the other modes is left out at compile time. */
+template <bool CNT, bool PLAIN = false>
 __device__ __forceinline__ void path_fresh(const RenderArgs &ra, Path &q, int i, int j, int kend, Cnt &cnt) {
     if (!q.fresh || q.finished) return;
     if (q.k >= kend) { q.finished = true; return; }
@@ -1157,7 +1159,7 @@ __device__ __forceinline__ void path_fresh(const RenderArgs &ra, Path &q, int i,
     if (CNT) cnt.paths++;
     q.key = rng_key(ra.seed_mixed, (uint32_t)(i * p.W + j), (uint32_t)q.k);
     q.ctr = 0;
-    if (p.flags & RT_F_NO_JITTER) { /* Ray r(C, u), raytracer.cpp:1482 */
+    if (!PLAIN && (p.flags & RT_F_NO_JITTER)) { /* Ray r(C, u), raytracer.cpp:1482 */
         V3 d = mk(j - p.W / 2 + 0.5, i - p.H / 2 + 0.5, cam.zdist);
         d = unit(d);
         const V3 dir = add(add(smul(d.x, right), smul(d.y, up)), smul(d.z, view));
@@ -1194,11 +1196,11 @@ __device__ __forceinline__ void path_fresh(const RenderArgs &ra, Path &q, int i,
 /* One step of Scene::getColor (raytracer.cpp:953-1093) given the answers of the rays that were traced: first the
  * shadow ray of the pending diffuse vertex (hs), then the path segment (h), in the order the recursion adds their
  * terms. Leaves the next ray(s) in the state or ends the sample (fresh = true). */
-template <bool CNT>
+template <bool CNT, bool PLAIN = false>
 __device__ __forceinline__ void path_advance(const DScene &sc, const rt_sphere *sph, const RenderArgs &ra, Path &q, bool inter,
                                              const HitRec &h, bool inter_s, const HitRec &hs, Cnt &cnt) {
     const rt_params &p = ra.p;
-    const uint32_t fl = p.flags;
+    const uint32_t fl = PLAIN ? 0u : p.flags;
     const double epsilon = p.epsilon;
     bool done = false;
     if (q.shadow) {
@@ -1358,7 +1360,7 @@ __device__ __forceinline__ bool slot_pixel(const RenderArgs &ra, int64_t slot, i
  * per request; a lane keeps its pixel for all nk samples (added in order, raytracer.cpp:1464-1486), writes the
  * sum and takes the next free slot. Because lanes re-fill independently, the wave's pool stays full until the
  * whole frame runs out of pixels, instead of idling while the longest of 64 fixed pixels finishes. */
-template <bool CNT, bool SPH>
+template <bool CNT, bool SPH, bool PLAIN>
 __device__ __forceinline__ void render_persistent(const DScene &sc, const DScene &cold, WaveLDS *w, const rt_sphere *sph, const RootRec *roots,
                                                   const RenderArgs &ra, int k0, int nk, double *accum, int *next_slot, int n_slots,
                                                   Cnt &cnt) {
@@ -1400,7 +1402,7 @@ __device__ __forceinline__ void render_persistent(const DScene &sc, const DScene
             const int taken = __popcll(need);
             cur = (cur + taken < end) ? cur + taken : end;
         }
-        path_fresh<CNT>(ra, q, i, j, kend, cnt);
+        path_fresh<CNT, PLAIN>(ra, q, i, j, kend, cnt);
         if (__ballot(!q.finished) == 0ull) {
             if (__ballot(!exhausted || have) == 0ull) break;
             continue; /* nothing to trace this round: only bookkeeping (pixels ended or were just assigned) */
@@ -1409,9 +1411,9 @@ __device__ __forceinline__ void render_persistent(const DScene &sc, const DScene
         HitRec h, hs;
         const RayQ qa = RayQ{!q.finished && q.segment, q.rC, q.ru, 1E10, false};
         const RayQ qb = RayQ{!q.finished && q.shadow, q.shC, q.shU, q.sh_limit, true};
-        scene_closest_wave<CNT, SPH>(sc, cold, w, sph, roots, qa, qb, !(ra.p.flags & RT_F_NO_PRUNE), h, hs, cnt);
+        scene_closest_wave<CNT, SPH>(sc, cold, w, sph, roots, qa, qb, PLAIN ? true : !(ra.p.flags & RT_F_NO_PRUNE), h, hs, cnt);
         if (CNT) sp0 = RT_STAMP();
-        if (!q.finished) path_advance<CNT>(cold, sph, ra, q, h.obj != INT32_MAX, h, hs.obj != INT32_MAX, hs, cnt);
+        if (!q.finished) path_advance<CNT, PLAIN>(cold, sph, ra, q, h.obj != INT32_MAX, h, hs.obj != INT32_MAX, hs, cnt);
         if (CNT) cnt.cyc_shade += RT_STAMP() - sp0;
     }
 }

@@ -9,6 +9,6 @@ timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_BRANCH SQ_IFETCH SQ_IFETCH_LEVEL SQ
 timeout -s KILL 200 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_BUSY_CYCLES SQC_DCACHE_REQ SQC_DCACHE_MISSES SQC_TC_STALL SQC_TC_INST_REQ --output-format csv -d $O/b -- $B > $O/b.log 2>&1
 for x in a b; do python3 tools/pmc_summary.py $O/$x > $O/$x.json; python3 - $O/$x.json <<'PY'
 import json,sys
-d=json.load(open(sys.argv[1])); k=[x for x in d if "rt_render_kernel<false>" in x][0]; print(json.dumps(d[k]))
+d=json.load(open(sys.argv[1])); k=[x for x in d if "rt_render_kernel<false, true>" in x][0]; print(json.dumps(d[k]))
 PY
 done

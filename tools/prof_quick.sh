@@ -15,6 +15,6 @@ python3 - $O <<'PY'
 import json,sys
 for f in ("pmc1","pmc2"):
     d=json.load(open(sys.argv[1]+"/"+f+".json"))
-    k=[x for x in d if "rt_render_kernel<false>" in x][0]
+    k=[x for x in d if "rt_render_kernel<false, true>" in x][0]
     print(f, json.dumps(d[k]))
 PY
