@@ -323,8 +323,9 @@ struct Tri3 {
     V3 A, e1, e2;
     int32_t id; /* rt_tri::orig_id */
 };
-__device__ __forceinline__ Tri3 tri_load(const rt_tri *base, uint32_t pos) {
-    const rt_tri *tr = base + pos;
+template <typename P>
+__device__ __forceinline__ Tri3 tri_load(P base, uint32_t pos) {
+    const auto tr = base + pos;
     Tri3 t;
     t.A = ld3(tr->A);
     t.e1 = ld3(tr->e1);
@@ -392,6 +393,17 @@ __device__ __forceinline__ const rt_sphere *lds_spheres(const WaveLDS *w, int no
 }
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+/* A scene array's pointer that was read from the LDS copy of the scene: the compiler cannot see where it points and would
+ * use flat loads, which wait on the LDS counter as well. All scene arrays are in global memory. */
+#if defined(__HIP_DEVICE_COMPILE__)
+template <typename T>
+__device__ __forceinline__ const T __attribute__((address_space(1))) *in_global(const T *p) {
+    return (const T __attribute__((address_space(1))) *)p;
+}
+#else
+template <typename T>
+__device__ __forceinline__ const T *in_global(const T *p) { return p; }
+#endif
 /* the lanes for which p holds, as the compiler's own lane mask (the __ballot of the HIP headers goes through an integer
  * compare: two more instructions per call) */
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -609,17 +621,17 @@ __device__ __forceinline__ void rays_end(const DScene &sc, WaveLDS *w, int lane,
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         const uint32_t p0 = tr[r] ? (uint32_t)pos[r] : 0u;
-        T[r] = tri_load(sc.tris, p0);
-        mesh[r] = sc.tris[p0].mesh;
-        if (r == 0) group = sc.attrs[p0].group; /* only a path segment's hit is shaded */
-        if (own) leaf[r] = sc.tri_leaf[p0];
+        T[r] = tri_load(in_global(sc.tris), p0);
+        mesh[r] = in_global(sc.tris)[p0].mesh;
+        if (r == 0) group = in_global(sc.attrs)[p0].group; /* only a path segment's hit is shaded */
+        if (own) leaf[r] = in_global(sc.tri_leaf)[p0];
     }
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         if (!tr[r]) mesh[r] = ph[r] ? pos[r] - RT_PHANTOM_BASE : 0;
-        oid[r] = sc.meshes[mesh[r]].object_id;
+        oid[r] = in_global(sc.meshes)[mesh[r]].object_id;
         if (own) {
-            const float *b = sc.leaf_box32 + (size_t)leaf[r] * 6;
+            const float *b = in_global(sc.leaf_box32) + (size_t)leaf[r] * 6;
             for (int a = 0; a < 6; a++) lb[r][a] = b[a];
         }
     }
@@ -1072,17 +1084,17 @@ __device__ __forceinline__ void hit_surface(const DScene &sc, const rt_sphere *s
         s.flags = sph[h.prim].flags;
     } else if (h.prim < 0) { /* a mesh hit without a triangle: Scene::intersect's zero-initialised locals (:936) */
         s.P = s.N = s.albedo = mk(0, 0, 0);
-        s.flags = sc.meshes[h.mesh].flags;
+        s.flags = in_global(sc.meshes)[h.mesh].flags;
     } else { /* TriangleMesh::intersect :693-720 */
-        const rt_mesh &m = sc.meshes[h.mesh];
-        const rt_tri_attr *at = sc.attrs + h.prim;
+        const rt_mesh &m = in_global(sc.meshes)[h.mesh];
+        const rt_tri_attr *at = in_global(sc.attrs) + h.prim;
         double beta = h.beta, gamma = h.gamma, alpha = 1 - beta - gamma;
         V3 nn = add(add(smul(alpha, ld3(at->n[0])), smul(beta, ld3(at->n[1]))), smul(gamma, ld3(at->n[2])));
         s.N = unit(nn);
         s.P = add(C, u); /* raytracer.cpp:696: C + u, not C + t u */
         s.flags = m.flags;
         if (m.n_tex > 0) {
-            const rt_texture tx = sc.tex[m.first_tex + h.group];
+            const rt_texture tx = in_global(sc.tex)[m.first_tex + h.group];
             int H = tx.H, W = tx.W;
             double U = (alpha * at->uv[0][0] + beta * at->uv[1][0]) + gamma * at->uv[2][0];
             double V = (alpha * at->uv[0][1] + beta * at->uv[1][1]) + gamma * at->uv[2][1];
@@ -1095,8 +1107,9 @@ __device__ __forceinline__ void hit_surface(const DScene &sc, const rt_sphere *s
             if (uvx < 0) uvx += W;
             if (uvy < 0) uvy += H;
             uvy = H - uvy - 1;
-            const uint8_t *px = sc.texels + tx.offset + ((int64_t)uvy * W + uvx) * 3;
-            s.albedo = mk(sc.lut[px[0]], sc.lut[px[1]], sc.lut[px[2]]);
+            const uint8_t *px = in_global(sc.texels) + tx.offset + ((int64_t)uvy * W + uvx) * 3;
+            const double *lut = in_global(sc.lut);
+            s.albedo = mk(lut[px[0]], lut[px[1]], lut[px[2]]);
         } else {
             s.albedo = ld3(m.albedo);
         }
