@@ -61,7 +61,10 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_kernel(DScene
      * copy in LDS where it is needed */
     if (threadIdx.x == 0) { w->sc = sc; w->ra = ra; }
     wave_sync();
-    render_persistent<CNT, false, PLAIN>(sc, w->sc, w, sph, roots, w->ra, k0, nk, accum, next_slot, n_slots, cnt);
+    /* this kernel is launched for sphere lists that wave_setup has staged in LDS (longer ones have a tree and the other
+     * kernel): saying so lets the sphere tests read them with LDS instructions */
+    const rt_sphere __attribute__((address_space(3))) *sph_lds = (const rt_sphere __attribute__((address_space(3))) *)sph;
+    render_persistent<CNT, false, PLAIN>(sc, w->sc, w, sph_lds, roots, w->ra, k0, nk, accum, next_slot, n_slots, cnt);
     if (CNT) flush_counters(cnt, counters);
 }
 

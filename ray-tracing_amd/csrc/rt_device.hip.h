@@ -156,7 +156,8 @@ struct V3 {
     double x, y, z;
 };
 __device__ __forceinline__ V3 mk(double x, double y, double z) { return V3{x, y, z}; }
-__device__ __forceinline__ V3 ld3(const double *p) { return V3{p[0], p[1], p[2]}; }
+template <typename P>
+__device__ __forceinline__ V3 ld3(P p) { return V3{p[0], p[1], p[2]}; } /* P: a pointer to three doubles, in any address space */
 /* Vector operators, raytracer.cpp:62-110 */
 __device__ __forceinline__ V3 add(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
 __device__ __forceinline__ V3 sub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
@@ -462,7 +463,9 @@ struct RayQ {
 };
 
 /* Sphere::intersect, raytracer.cpp:883-918, and Scene::intersect's choice (:938: the lowest objectId wins an exact tie) */
-__device__ __forceinline__ void sphere_test(const rt_sphere *sph, int s, V3 C, V3 u, HitRec &h) {
+/* SP (here and below): the type of the pointer to the sphere list - in LDS for the render kernel of short lists, anywhere otherwise */
+template <typename SP>
+__device__ __forceinline__ void sphere_test(SP sph, int s, V3 C, V3 u, HitRec &h) {
     V3 O = ld3(sph[s].O);
     double R = sph[s].R;
     int32_t oid = sph[s].object_id;
@@ -505,7 +508,8 @@ __device__ __forceinline__ void sphere_walk_begin(const DScene &sc, const RayQ &
     sw.layout = sc.sph_nodes + (size_t)((q.u.x < 0 ? 1 : 0) | (q.u.y < 0 ? 2 : 0) | (q.u.z < 0 ? 4 : 0)) * (size_t)sc.n_sph_nodes;
     sw.i = on ? 0 : sc.n_sph_nodes;
 }
-__device__ __forceinline__ void sphere_walk_step(const rt_sphere *sph, const RayQ &q, const SphNode &nd, SphereWalk &sw, HitRec &h) {
+template <typename SP>
+__device__ __forceinline__ void sphere_walk_step(SP sph, const RayQ &q, const SphNode &nd, SphereWalk &sw, HitRec &h) {
     bool hit, unsure;
     float tlo;
     box_fast_f(nd.box[0], nd.box[1], nd.box[2], nd.box[3], nd.box[4], nd.box[5], sw.kf, hit, unsure, tlo);
@@ -520,7 +524,8 @@ __device__ __forceinline__ void sphere_walk_step(const rt_sphere *sph, const Ray
  * matter - nearer than the closest hit so far and than tmax -, get the exact test; the winner is the same, because
  * the choice among tested spheres (smallest t, then smallest objectId) does not depend on their order. Rays outside
  * the tree's reach are left to ray_begin (done_* stays false). */
-__device__ __forceinline__ void spheres_walk2(const DScene &sc, const rt_sphere *sph, const RayQ &qa, const RayQ &qb, HitRec &ha, HitRec &hb, bool &done_a,
+template <typename SP>
+__device__ __forceinline__ void spheres_walk2(const DScene &sc, SP sph, const RayQ &qa, const RayQ &qb, HitRec &ha, HitRec &hb, bool &done_a,
                                               bool &done_b) {
     hit_none(ha);
     hit_none(hb);
@@ -544,8 +549,8 @@ __device__ __forceinline__ void spheres_walk2(const DScene &sc, const rt_sphere 
 }
 
 /* Spheres for one ray and the ray's entry in the pool's tables. */
-template <bool CNT, bool SPH>
-__device__ __forceinline__ void ray_begin(const DScene &sc, WaveLDS *w, const rt_sphere *sph, int slot, const RayQ &q, bool prune, bool spheres_done,
+template <bool CNT, bool SPH, typename SP>
+__device__ __forceinline__ void ray_begin(const DScene &sc, WaveLDS *w, SP sph, int slot, const RayQ &q, bool prune, bool spheres_done,
                                           HitRec &h, Cnt &cnt) {
     if (!spheres_done) hit_none(h);
     if (!q.active) return;
@@ -751,8 +756,8 @@ __device__ __forceinline__ void wide_children(const DScene &sc, WaveLDS *w, int 
  * 64 lanes together; active rays get their closest hit. */
 /* SPH: compiled with the walk through the sphere tree (scenes with long sphere lists); without it the code for short
  * lists is exactly what it was before the tree existed. */
-template <bool CNT, bool SPH>
-__device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScene &cold, WaveLDS *w, const rt_sphere *sph, const RootRec *roots, const RayQ &qa0, const RayQ &qb0,
+template <bool CNT, bool SPH, typename SP>
+__device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScene &cold, WaveLDS *w, SP sph, const RootRec *roots, const RayQ &qa0, const RayQ &qb0,
                                                    bool prune, HitRec &ha, HitRec &hb, Cnt &cnt) {
     const int lane = lane_id();
     uint64_t st0 = 0;
@@ -1075,7 +1080,8 @@ struct Surf {
 };
 
 /* what Scene::intersect hands back for the winning object: P, N, colour, material */
-__device__ __forceinline__ void hit_surface(const DScene &sc, const rt_sphere *sph, V3 C, V3 u, const HitRec &h, Surf &s) {
+template <typename SP>
+__device__ __forceinline__ void hit_surface(const DScene &sc, SP sph, V3 C, V3 u, const HitRec &h, Surf &s) {
     if (h.mesh < 0) { /* Sphere::intersect :914-915 */
         V3 O = ld3(sph[h.prim].O);
         s.P = add(C, smul(h.t, u));
@@ -1209,8 +1215,8 @@ __device__ __forceinline__ void path_fresh(const RenderArgs &ra, Path &q, int i,
 /* One step of Scene::getColor (raytracer.cpp:953-1093) given the answers of the rays that were traced: first the
  * shadow ray of the pending diffuse vertex (hs), then the path segment (h), in the order the recursion adds their
  * terms. Leaves the next ray(s) in the state or ends the sample (fresh = true). */
-template <bool CNT, bool PLAIN = false>
-__device__ __forceinline__ void path_advance(const DScene &sc, const rt_sphere *sph, const RenderArgs &ra, Path &q, bool inter,
+template <bool CNT, bool PLAIN = false, typename SP>
+__device__ __forceinline__ void path_advance(const DScene &sc, SP sph, const RenderArgs &ra, Path &q, bool inter,
                                              const HitRec &h, bool inter_s, const HitRec &hs, Cnt &cnt) {
     const rt_params &p = ra.p;
     const uint32_t fl = PLAIN ? 0u : p.flags;
@@ -1334,8 +1340,8 @@ __device__ __forceinline__ void path_advance(const DScene &sc, const rt_sphere *
 /* Single-kernel form: sum of the radiance of samples k0 .. k0+nk-1 of pixel (i, j), added in that
  * order (the k loop of raytracer.cpp:1464-1486). Called by all 64 lanes of the wave; lanes with
  * live == false only help in the pool. */
-template <bool CNT, bool SPH>
-__device__ __forceinline__ V3 trace_pixel(const DScene &sc, const DScene &cold, WaveLDS *w, const rt_sphere *sph, const RootRec *roots, const RenderArgs &ra, bool live, int i,
+template <bool CNT, bool SPH, typename SP>
+__device__ __forceinline__ V3 trace_pixel(const DScene &sc, const DScene &cold, WaveLDS *w, SP sph, const RootRec *roots, const RenderArgs &ra, bool live, int i,
                                           int j, int k0, int nk, Cnt &cnt) {
     Path q;
     path_begin(q, k0, live);
@@ -1373,8 +1379,8 @@ __device__ __forceinline__ bool slot_pixel(const RenderArgs &ra, int64_t slot, i
  * per request; a lane keeps its pixel for all nk samples (added in order, raytracer.cpp:1464-1486), writes the
  * sum and takes the next free slot. Because lanes re-fill independently, the wave's pool stays full until the
  * whole frame runs out of pixels, instead of idling while the longest of 64 fixed pixels finishes. */
-template <bool CNT, bool SPH, bool PLAIN>
-__device__ __forceinline__ void render_persistent(const DScene &sc, const DScene &cold, WaveLDS *w, const rt_sphere *sph, const RootRec *roots,
+template <bool CNT, bool SPH, bool PLAIN, typename SP>
+__device__ __forceinline__ void render_persistent(const DScene &sc, const DScene &cold, WaveLDS *w, SP sph, const RootRec *roots,
                                                   const RenderArgs &ra, int k0, int nk, double *accum, int *next_slot, int n_slots,
                                                   Cnt &cnt) {
     Path q;
