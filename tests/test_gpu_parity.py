@@ -236,6 +236,53 @@ def test_stochastic_per_sample(gpu, rta, scenes, ob, name, kw):
     assert bad <= max(2, len(ijk) // 2000), (bad, len(ijk), np.sort(rel)[-5:])
 
 
+@pytest.mark.parametrize("kind", ["light_only", "one_triangle", "coincident_triangles", "mesh_behind_camera"])
+def test_minimal_scenes(gpu, rta, scenes, ob, probe_mode, kind):
+    """The smallest scenes the reference can hold: the light sphere alone (every other ray misses), a mesh of one
+    triangle (its BVH is a single leaf), a mesh whose triangles all coincide (no split separates them), a mesh no camera ray reaches."""
+    W = 48
+    s = rta.Scene(I=6e9, L=(-10, 50, 40))
+    s.add(rta.Sphere(s.L, 5, (1, 1, 1)))
+    if kind != "light_only":
+        if kind == "one_triangle":
+            v = np.array([[-20, -5, -10], [20, -5, -12], [0, 25, -8]], np.float64)
+            nt = 1
+        elif kind == "coincident_triangles":
+            v = np.tile(np.array([[-20, -5, -10], [20, -5, -12], [0, 25, -8]], np.float64), (9, 1))
+            nt = 9
+        else:
+            v = np.array([[-20, -5, 90], [20, -5, 92], [0, 25, 95], [3, 4, 99]], np.float64)
+            nt = 2
+        n = np.tile(np.array([[0.0, 0.0, 1.0]]), (len(v), 1))
+        uv = np.zeros((len(v), 2))
+        ix = np.zeros((nt, 10), np.int32)
+        for t in range(nt):
+            a = (3 * t) % (len(v) - 2)
+            ix[t, 0:3] = ix[t, 3:6] = ix[t, 6:9] = (a, a + 1, a + 2)
+        m = rta.TriangleMesh((0.2, 0.9, 0.4))
+        m.set_raw(v, n, uv, ix)
+        m.buildBVH()
+        s.add(m)
+    cam = scenes.make_camera((0, 30, 55), 60.0, -25.0, 0.0, W)
+    orc = ob.OracleScene(scenes.export_objects(s), s.I, s.L)
+    gpu.upload(s)
+    rays, _ = ob.primary_rays(cam, W, W)
+    extra = scenes.rays_into_box(2000, 3, (-30, -10, -20), (30, 60, 60), (-25, -10, -15), (25, 55, 45))
+    rays = np.ascontiguousarray(np.concatenate([rays, extra]))
+    g, o = gpu.intersect_rays(rays), orc.intersect_rays(rays)
+    if kind in ("one_triangle", "coincident_triangles"):
+        assert (o["tri"] >= 0).sum() > 50
+    _check_hits(g, o)
+    p = rta.make_params(W, W, 2)
+    ijk = np.array([(i, j, k) for i in range(0, W, 2) for j in range(0, W, 2) for k in range(2)], np.int32)
+    rel = _rel_err(gpu.sample_radiance(cam, p, ijk), orc.sample_radiance(cam, p, ijk))
+    assert (rel > 1e-9).sum() <= 2, np.sort(rel)[-5:]
+    gpu.accum_clear(W, W)
+    gpu.render(cam, p)
+    img = gpu.resolve(W, W, 2)
+    assert img.shape == (W, W, 3)
+
+
 @pytest.mark.parametrize("n_spheres", [58, 59, 150])  # 64 objects in all: the longest list staged in LDS; 65 and 156: the tree
 def test_many_spheres_and_one_big_mesh(gpu, rta, scenes, ob, probe_mode, n_spheres):
     """cfg5 at reduced size: more spheres than the per-wave LDS staging holds - they are reached through a tree
