@@ -56,7 +56,7 @@ namespace rtd {
 #define RT_LEAF_CAP 320           /* leaf-item stack entries */
 #endif
 #ifndef RT_LEAF_TRIGGER
-#define RT_LEAF_TRIGGER 64        /* pending leaf items that make the next pool step a triangle step */
+#define RT_LEAF_TRIGGER 32        /* pending leaf items that make the next pool step a triangle step */
 #endif
 #define RT_RAY_SLOTS 128          /* rays of one query: two per lane (slot = lane, 64 + lane) */
 #define RT_NODE_BITS 25           /* record-index / leaf-count bits in a pool item (the ray slot takes the top 7) */
@@ -855,7 +855,8 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScen
         }
         /* one pool step: up to 64 items */
         {
-            const bool do_leaf = (n_leaves >= RT_LEAF_TRIGGER) || (n_nodes == 0) || (n_leaves + (own ? 4 : 2) * RT_WAVE > RT_LEAF_CAP);
+            const bool do_leaf = (n_leaves >= RT_LEAF_TRIGGER) || (n_nodes == 0) ||
+                                 (n_leaves + (own ? 4 : 2) * RT_WAVE > RT_LEAF_CAP);
             if (do_leaf) {
                 /* 64 triangles per step whichever leaves they sit in: the top m <= 64 leaf items are
                  * (first, count) ranges; a prefix sum of the counts gives every item its slots, slot s (=
