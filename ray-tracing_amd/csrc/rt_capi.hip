@@ -50,7 +50,7 @@ __device__ __forceinline__ WaveLDS *wave_setup(const DScene &sc, unsigned char *
 /* CNT: with work counters. PLAIN: no mode flag of rt_params is set (what a production render uses): the other modes'
  * code is left out. */
 template <bool CNT, bool PLAIN = false>
-__global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_kernel(DScene sc, RenderArgs ra, int k0, int nk, double *accum,
+__global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_kernel(DScene sc, RenderArgs ra, int k0, int nk, int chunk, double *accum,
                                                              rt_counters *counters, int *next_slot, int n_slots) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const rt_sphere *sph;
@@ -64,13 +64,13 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_kernel(DScene
     /* this kernel is launched for sphere lists that wave_setup has staged in LDS (longer ones have a tree and the other
      * kernel): saying so lets the sphere tests read them with LDS instructions */
     const rt_sphere __attribute__((address_space(3))) *sph_lds = (const rt_sphere __attribute__((address_space(3))) *)sph;
-    render_persistent<CNT, false, PLAIN>(sc, w->sc, w, sph_lds, roots, w->ra, k0, nk, accum, next_slot, n_slots, cnt);
+    render_persistent<CNT, false, PLAIN>(sc, w->sc, w, sph_lds, roots, w->ra, k0, nk, chunk, accum, next_slot, n_slots, cnt);
     if (CNT) flush_counters(cnt, counters);
 }
 
 /* the same for scenes whose sphere list is too long for LDS: with the walk through the sphere tree compiled in */
 template <bool CNT>
-__global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_spheres_kernel(DScene sc, RenderArgs ra, int k0, int nk, double *accum,
+__global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_spheres_kernel(DScene sc, RenderArgs ra, int k0, int nk, int chunk, double *accum,
                                                                      rt_counters *counters, int *next_slot, int n_slots) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const rt_sphere *sph;
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_spheres_kerne
     Cnt cnt = {};
     if (threadIdx.x == 0) { w->sc = sc; w->ra = ra; }
     wave_sync();
-    render_persistent<CNT, true, false>(sc, w->sc, w, sph, roots, w->ra, k0, nk, accum, next_slot, n_slots, cnt);
+    render_persistent<CNT, true, false>(sc, w->sc, w, sph, roots, w->ra, k0, nk, chunk, accum, next_slot, n_slots, cnt);
     if (CNT) flush_counters(cnt, counters);
 }
 
@@ -781,6 +781,10 @@ static int check_render_args(rt_ctx *c, const rt_camera *cam, const rt_params *p
 
 /* samples per kernel launch: long renders are cut into several launches of bounded duration */
 static const int kSppPerLaunch = 64;
+#ifndef RT_SPP_PER_UNIT
+#define RT_SPP_PER_UNIT 8
+#endif
+static const int kSppPerUnit = RT_SPP_PER_UNIT; /* samples of one pixel that a lane takes at a time on large frames */
 
 int rt_render(rt_ctx *c, const rt_camera *cam, const rt_params *p, double *accum) {
     if (!c) return RT_E_INVALID;
@@ -805,17 +809,22 @@ int rt_render(rt_ctx *c, const rt_camera *cam, const rt_params *p, double *accum
         const unsigned pgrid = grid < (unsigned)(c->n_cus * c->waves_per_cu) ? grid : (unsigned)(c->n_cus * c->waves_per_cu);
         for (int k = 0; k < p->spp; k += kSppPerLaunch) {
             const int nk = (p->spp - k < kSppPerLaunch) ? (p->spp - k) : kSppPerLaunch;
+            /* Work units of kSppPerUnit samples when the frame has several pixels per resident lane: the launch then
+             * ends within one short unit per lane instead of one whole pixel. Smaller frames keep one unit per pixel
+             * (units of one pixel would run side by side and their sums would be added in an order that can vary). */
+            int chunk = nk;
+            if ((int64_t)n_slots >= 4 * (int64_t)pgrid * RT_WAVE && (int64_t)n_slots * ((nk + kSppPerUnit - 1) / kSppPerUnit) <= 0x7fffffffLL) chunk = kSppPerUnit;
             HIPCHK(c, hipMemsetAsync(c->d_next_slot, 0, sizeof(int), c->stream));
             if (c->sc.sph_nodes != nullptr && (p->flags & RT_F_COUNTERS))
-                hipLaunchKernelGGL(rt_render_spheres_kernel<true>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, accum, c->d_counters, c->d_next_slot, n_slots);
+                hipLaunchKernelGGL(rt_render_spheres_kernel<true>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, c->d_counters, c->d_next_slot, n_slots);
             else if (c->sc.sph_nodes != nullptr)
-                hipLaunchKernelGGL(rt_render_spheres_kernel<false>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, accum, c->d_counters, c->d_next_slot, n_slots);
+                hipLaunchKernelGGL(rt_render_spheres_kernel<false>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, c->d_counters, c->d_next_slot, n_slots);
             else if (p->flags == 0)
-                hipLaunchKernelGGL((rt_render_kernel<false, true>), dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, accum, c->d_counters, c->d_next_slot, n_slots);
+                hipLaunchKernelGGL((rt_render_kernel<false, true>), dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, c->d_counters, c->d_next_slot, n_slots);
             else if (p->flags & RT_F_COUNTERS)
-                hipLaunchKernelGGL(rt_render_kernel<true>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, accum, c->d_counters, c->d_next_slot, n_slots);
+                hipLaunchKernelGGL(rt_render_kernel<true>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, c->d_counters, c->d_next_slot, n_slots);
             else
-                hipLaunchKernelGGL(rt_render_kernel<false>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, accum, c->d_counters, c->d_next_slot, n_slots);
+                hipLaunchKernelGGL(rt_render_kernel<false>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, c->d_counters, c->d_next_slot, n_slots);
             HIPCHK(c, hipGetLastError());
             c->last_launches++;
         }

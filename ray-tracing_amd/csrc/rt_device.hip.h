@@ -1382,11 +1382,17 @@ __device__ __forceinline__ bool slot_pixel(const RenderArgs &ra, int64_t slot, i
  * whole frame runs out of pixels, instead of idling while the longest of 64 fixed pixels finishes. */
 template <bool CNT, bool SPH, bool PLAIN, typename SP>
 __device__ __forceinline__ void render_persistent(const DScene &sc, const DScene &cold, WaveLDS *w, SP sph, const RootRec *roots,
-                                                  const RenderArgs &ra, int k0, int nk, double *accum, int *next_slot, int n_slots,
+                                                  const RenderArgs &ra, int k0, int nk, int chunk, double *accum, int *next_slot, int n_slots,
                                                   Cnt &cnt) {
     Path q;
     path_begin(q, k0, false); /* finished: no pixel yet */
     const int kend = k0 + nk;
+    /* A unit of work is `chunk` consecutive samples of one pixel; the units are numbered chunk by chunk over the frame
+     * (n_slots pixel slots each). Short units keep the end of a launch short: once the counter runs out, a wave only has
+     * to finish the units its lanes hold. With more than one unit per pixel the sums are added atomically. */
+    const int n_chunks = (nk + chunk - 1) / chunk;
+    const int n_total = n_slots * n_chunks;
+    int kend_l = kend;
     bool have = false, exhausted = false;
     int i = 0, j = 0;
     int cur = 0, end = 0; /* wave-uniform: the part of the last tile request not handed out yet */
@@ -1395,9 +1401,15 @@ __device__ __forceinline__ void render_persistent(const DScene &sc, const DScene
         if (CNT) sp0 = RT_STAMP();
         if (have && q.finished) { /* all samples of this lane's pixel are in q.acc */
             double *px = accum + ((int64_t)i * ra.p.W + j) * 3;
-            px[0] = px[0] + q.acc.x;
-            px[1] = px[1] + q.acc.y;
-            px[2] = px[2] + q.acc.z;
+            if (n_chunks > 1) {
+                unsafeAtomicAdd(px, q.acc.x);
+                unsafeAtomicAdd(px + 1, q.acc.y);
+                unsafeAtomicAdd(px + 2, q.acc.z);
+            } else {
+                px[0] = px[0] + q.acc.x;
+                px[1] = px[1] + q.acc.y;
+                px[2] = px[2] + q.acc.z;
+            }
             have = false;
         }
         const unsigned long long need = __ballot(!have && !exhausted);
@@ -1406,23 +1418,26 @@ __device__ __forceinline__ void render_persistent(const DScene &sc, const DScene
                 int base = 0;
                 if (lane_id() == 0) base = atomicAdd(next_slot, RT_WAVE);
                 cur = uni(base);
-                end = cur + RT_WAVE < n_slots ? cur + RT_WAVE : n_slots;
-                if (cur >= n_slots) { cur = end = n_slots; }
+                end = cur + RT_WAVE < n_total ? cur + RT_WAVE : n_total;
+                if (cur >= n_total) { cur = end = n_total; }
             }
             if (!have && !exhausted) {
                 const int mine = cur + rank_in(need);
-                if (cur >= n_slots) {
+                if (cur >= n_total) {
                     exhausted = true;
                 } else if (mine < end) {
-                    const bool live = slot_pixel(ra, mine, i, j);
-                    path_begin(q, k0, live);
+                    const int c = mine / n_slots;
+                    const bool live = slot_pixel(ra, mine - c * n_slots, i, j);
+                    const int ks = k0 + c * chunk;
+                    kend_l = ks + chunk < kend ? ks + chunk : kend;
+                    path_begin(q, ks, live);
                     have = live; /* a slot outside the rectangle is skipped */
                 }
             }
             const int taken = __popcll(need);
             cur = (cur + taken < end) ? cur + taken : end;
         }
-        path_fresh<CNT, PLAIN>(ra, q, i, j, kend, cnt);
+        path_fresh<CNT, PLAIN>(ra, q, i, j, kend_l, cnt);
         if (__ballot(!q.finished) == 0ull) {
             if (__ballot(!exhausted || have) == 0ull) break;
             continue; /* nothing to trace this round: only bookkeeping (pixels ended or were just assigned) */

@@ -143,6 +143,21 @@ class TestFullSize:
         b = gpu.accum_download(W, W)
         assert np.allclose(a, b, rtol=1e-13, atol=1e-9)
 
+    def test_sample_units_add_up(self, gpu, rta, full):
+        """On a frame this large a launch hands out a pixel's samples in units of a few samples (added to the
+        accumulator atomically): 20 samples in one call == the same samples rendered in calls too short to be cut."""
+        s, cam, flags = full
+        W = 1024
+        gpu.accum_clear(W, W)
+        gpu.render(cam, rta.make_params(W, W, 20, flags=flags))
+        a = gpu.accum_download(W, W)
+        gpu.accum_clear(W, W)
+        for k0, n in ((0, 5), (5, 5), (10, 5), (15, 5)):
+            gpu.render(cam, rta.make_params(W, W, n, spp_offset=k0, flags=flags))
+        b = gpu.accum_download(W, W)
+        assert np.allclose(a, b, rtol=1e-13, atol=1e-9, equal_nan=True)
+        assert (a > 0).mean() > 0.9
+
     def test_pruned_equals_unpruned_and_counted(self, gpu, rta, full):
         s, cam, flags = full
         W = 1024
