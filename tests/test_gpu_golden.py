@@ -157,6 +157,9 @@ class TestFullSize:
         b = gpu.accum_download(W, W)
         assert np.allclose(a, b, rtol=1e-13, atol=1e-9, equal_nan=True)
         assert (a > 0).mean() > 0.9
+        gpu.accum_clear(W, W)
+        gpu.render(cam, rta.make_params(W, W, 20, flags=flags))
+        assert np.array_equal(a, gpu.accum_download(W, W), equal_nan=True)  # units of one pixel end a whole frame apart: same order
 
     def test_pruned_equals_unpruned_and_counted(self, gpu, rta, full):
         s, cam, flags = full
