@@ -183,3 +183,19 @@ class TestFullSize:
         g, o = gpu.sample_radiance(cam, p, ijk), orc.sample_radiance(cam, p, ijk)
         rel = np.abs(g - o) / np.maximum(np.abs(o), 1e-3)
         assert (rel > 1e-9).sum() <= 3, np.sort(rel.ravel())[-5:]
+
+
+def test_sample_units_with_the_sphere_tree(gpu, rta, scenes):
+    """the same property for the kernel that walks the tree over a long sphere list (1024 x 1024: large enough for units)"""
+    W = 1024
+    s, cam, flags = scenes.stress(W=W, n_tris=20000, n_spheres=150)[:3]
+    gpu.upload(s)
+    gpu.accum_clear(W, W)
+    gpu.render(cam, rta.make_params(W, W, 12, flags=flags))
+    a = gpu.accum_download(W, W)
+    gpu.accum_clear(W, W)
+    for k0 in (0, 4, 8):
+        gpu.render(cam, rta.make_params(W, W, 4, spp_offset=k0, flags=flags))
+    b = gpu.accum_download(W, W)
+    assert np.allclose(a, b, rtol=1e-13, atol=1e-9, equal_nan=True)
+    assert (a > 0).mean() > 0.9
