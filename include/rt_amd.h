@@ -208,7 +208,11 @@ int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *scene);
  * spp_offset+spp-1, in that order) into accum[(i*W + j)*3 + c], i = the
  * reference's row index (not flipped).  accum is a DEVICE pointer to
  * W*H*3 doubles, or NULL for the context's own accumulator. Asynchronous on
- * the context's stream; rt_sync waits. */
+ * the context's stream; rt_sync waits.  The samples of a pixel are summed in
+ * order within a work unit (all samples of a launch of up to 64; 8 samples on
+ * rects with at least four pixels per resident lane - 524 288 pixels on an
+ * MI355X - where the unit sums are added with FP64 atomics: accum must then
+ * be ordinary device memory). */
 int rt_render(rt_ctx *ctx, const rt_camera *cam, const rt_params *p, double *accum);
 int rt_sync(rt_ctx *ctx);
 /* Zero / read back the context's own accumulator (W*H*3 doubles). */
