@@ -210,7 +210,7 @@ int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *scene);
  * W*H*3 doubles, or NULL for the context's own accumulator. Asynchronous on
  * the context's stream; rt_sync waits.  The samples of a pixel are summed in
  * order within a work unit (all samples of a launch of up to 64; 8 samples on
- * rects with at least four pixels per resident lane - 524 288 pixels on an
+ * rects with at least two pixels per resident lane - 262 144 pixels on an
  * MI355X - where the unit sums are added with FP64 atomics: accum must then
  * be ordinary device memory). */
 int rt_render(rt_ctx *ctx, const rt_camera *cam, const rt_params *p, double *accum);

@@ -50,7 +50,7 @@ __device__ __forceinline__ WaveLDS *wave_setup(const DScene &sc, unsigned char *
 /* CNT: with work counters. PLAIN: no mode flag of rt_params is set (what a production render uses): the other modes'
  * code is left out. */
 template <bool CNT, bool PLAIN = false>
-__global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_kernel(DScene sc, RenderArgs ra, int k0, int nk, int chunk, double *accum,
+__global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_kernel(DScene sc, RenderArgs ra, int k0, int nk, int chunk, double *accum, double *unit_sums,
                                                              rt_counters *counters, int *next_slot, int n_slots) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const rt_sphere *sph;
@@ -64,13 +64,13 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_kernel(DScene
     /* this kernel is launched for sphere lists that wave_setup has staged in LDS (longer ones have a tree and the other
      * kernel): saying so lets the sphere tests read them with LDS instructions */
     const rt_sphere __attribute__((address_space(3))) *sph_lds = (const rt_sphere __attribute__((address_space(3))) *)sph;
-    render_persistent<CNT, false, PLAIN>(sc, w->sc, w, sph_lds, roots, w->ra, k0, nk, chunk, accum, next_slot, n_slots, cnt);
+    render_persistent<CNT, false, PLAIN>(sc, w->sc, w, sph_lds, roots, w->ra, k0, nk, chunk, accum, unit_sums, next_slot, n_slots, cnt);
     if (CNT) flush_counters(cnt, counters);
 }
 
 /* the same for scenes whose sphere list is too long for LDS: with the walk through the sphere tree compiled in */
 template <bool CNT>
-__global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_spheres_kernel(DScene sc, RenderArgs ra, int k0, int nk, int chunk, double *accum,
+__global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_spheres_kernel(DScene sc, RenderArgs ra, int k0, int nk, int chunk, double *accum, double *unit_sums,
                                                                      rt_counters *counters, int *next_slot, int n_slots) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const rt_sphere *sph;
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_spheres_kerne
     Cnt cnt = {};
     if (threadIdx.x == 0) { w->sc = sc; w->ra = ra; }
     wave_sync();
-    render_persistent<CNT, true, false>(sc, w->sc, w, sph, roots, w->ra, k0, nk, chunk, accum, next_slot, n_slots, cnt);
+    render_persistent<CNT, true, false>(sc, w->sc, w, sph, roots, w->ra, k0, nk, chunk, accum, unit_sums, next_slot, n_slots, cnt);
     if (CNT) flush_counters(cnt, counters);
 }
 
@@ -139,6 +139,20 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_scan_test_kernel(const int *in, i
 }
 
 /* raytracer.cpp:1488-1501: /nbrays, pow 0.45, min(255, .), truncation to u8, row flip */
+/* Adds the sums of a launch's work units to the accumulator, unit by unit in sample order (what a sequence of calls of
+ * one unit each would have added): one thread per channel of a pixel of the rectangle. */
+__global__ void rt_units_add_kernel(double *accum, const double *unit_sums, int n_units, int W, int H, int j0, int i0, int rw, int rh) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)rw * rh * 3) return;
+    const int ch = (int)(t % 3);
+    const int64_t px = t / 3;
+    const int i = i0 + (int)(px / rw), j = j0 + (int)(px % rw);
+    const int64_t at = ((int64_t)i * W + j) * 3 + ch;
+    double a = accum[at];
+    for (int u = 0; u < n_units; u++) a = a + unit_sums[(int64_t)u * W * H * 3 + at];
+    accum[at] = a;
+}
+
 __global__ void rt_resolve_kernel(const double *accum, int W, int H, double spp, uint8_t *rgb) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= (int64_t)W * H) return;
@@ -174,6 +188,8 @@ struct rt_ctx {
     /* own accumulator */
     double *accum = nullptr;
     int accW = 0, accH = 0;
+    double *unit_sums = nullptr; /* sums of the work units of one launch: [unit of the pixel][H][W][3] */
+    size_t unit_sums_bytes = 0;
     rt_counters *d_counters = nullptr;
     int *d_overflow = nullptr;
     int *d_next_slot = nullptr;
@@ -271,6 +287,7 @@ void rt_destroy(rt_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_scene(c);
     if (c->accum) (void)hipFree(c->accum);
+    if (c->unit_sums) (void)hipFree(c->unit_sums);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_overflow) (void)hipFree(c->d_overflow);
     if (c->d_next_slot) (void)hipFree(c->d_next_slot);
@@ -784,6 +801,9 @@ static const int kSppPerLaunch = 64;
 #ifndef RT_SPP_PER_UNIT
 #define RT_SPP_PER_UNIT 8
 #endif
+#ifndef RT_UNIT_MIN_PX_PER_LANE
+#define RT_UNIT_MIN_PX_PER_LANE 2
+#endif
 static const int kSppPerUnit = RT_SPP_PER_UNIT; /* samples of one pixel that a lane takes at a time on large frames */
 
 int rt_render(rt_ctx *c, const rt_camera *cam, const rt_params *p, double *accum) {
@@ -809,23 +829,40 @@ int rt_render(rt_ctx *c, const rt_camera *cam, const rt_params *p, double *accum
         const unsigned pgrid = grid < (unsigned)(c->n_cus * c->waves_per_cu) ? grid : (unsigned)(c->n_cus * c->waves_per_cu);
         for (int k = 0; k < p->spp; k += kSppPerLaunch) {
             const int nk = (p->spp - k < kSppPerLaunch) ? (p->spp - k) : kSppPerLaunch;
-            /* Work units of kSppPerUnit samples when the frame has several pixels per resident lane: the launch then
-             * ends within one short unit per lane instead of one whole pixel. Smaller frames keep one unit per pixel
-             * (units of one pixel would run side by side and their sums would be added in an order that can vary). */
+            /* Work units of kSppPerUnit samples when the frame has at least RT_UNIT_MIN_PX_PER_LANE pixels per resident lane: the launch then
+             * ends within one short unit per lane instead of one whole pixel. On smaller frames most lanes hold a pixel of
+             * their own for the whole launch anyway. */
             int chunk = nk;
-            if ((int64_t)n_slots >= 4 * (int64_t)pgrid * RT_WAVE && (int64_t)n_slots * ((nk + kSppPerUnit - 1) / kSppPerUnit) <= 0x7fffffffLL) chunk = kSppPerUnit;
+            const int n_units = (nk + kSppPerUnit - 1) / kSppPerUnit;
+            if (n_units > 1 && (int64_t)n_slots >= RT_UNIT_MIN_PX_PER_LANE * (int64_t)pgrid * RT_WAVE && (int64_t)n_slots * n_units <= 0x7fffffffLL) {
+                const size_t need = (size_t)n_units * p->W * p->H * 3 * sizeof(double);
+                if (c->unit_sums_bytes < need) { /* kept for the following launches and calls */
+                    if (c->unit_sums) (void)hipFree(c->unit_sums);
+                    c->unit_sums = nullptr;
+                    c->unit_sums_bytes = 0;
+                    if (hipMalloc((void **)&c->unit_sums, need) == hipSuccess) c->unit_sums_bytes = need;
+                    else (void)hipGetLastError(); /* no room: whole pixels as units, slower at the end of the launch */
+                }
+                if (c->unit_sums_bytes >= need) chunk = kSppPerUnit;
+            }
             HIPCHK(c, hipMemsetAsync(c->d_next_slot, 0, sizeof(int), c->stream));
             if (c->sc.sph_nodes != nullptr && (p->flags & RT_F_COUNTERS))
-                hipLaunchKernelGGL(rt_render_spheres_kernel<true>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, c->d_counters, c->d_next_slot, n_slots);
+                hipLaunchKernelGGL(rt_render_spheres_kernel<true>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, c->unit_sums, c->d_counters, c->d_next_slot, n_slots);
             else if (c->sc.sph_nodes != nullptr)
-                hipLaunchKernelGGL(rt_render_spheres_kernel<false>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, c->d_counters, c->d_next_slot, n_slots);
+                hipLaunchKernelGGL(rt_render_spheres_kernel<false>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, c->unit_sums, c->d_counters, c->d_next_slot, n_slots);
             else if (p->flags == 0)
-                hipLaunchKernelGGL((rt_render_kernel<false, true>), dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, c->d_counters, c->d_next_slot, n_slots);
+                hipLaunchKernelGGL((rt_render_kernel<false, true>), dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, c->unit_sums, c->d_counters, c->d_next_slot, n_slots);
             else if (p->flags & RT_F_COUNTERS)
-                hipLaunchKernelGGL(rt_render_kernel<true>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, c->d_counters, c->d_next_slot, n_slots);
+                hipLaunchKernelGGL(rt_render_kernel<true>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, c->unit_sums, c->d_counters, c->d_next_slot, n_slots);
             else
-                hipLaunchKernelGGL(rt_render_kernel<false>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, c->d_counters, c->d_next_slot, n_slots);
+                hipLaunchKernelGGL(rt_render_kernel<false>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, c->unit_sums, c->d_counters, c->d_next_slot, n_slots);
             HIPCHK(c, hipGetLastError());
+            if (chunk < nk) {
+                const int64_t nthr = (int64_t)rw * rh * 3;
+                hipLaunchKernelGGL(rt_units_add_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, c->stream, accum, c->unit_sums, n_units, p->W, p->H,
+                                   ra.j0, ra.i0, rw, rh);
+                HIPCHK(c, hipGetLastError());
+            }
             c->last_launches++;
         }
     }

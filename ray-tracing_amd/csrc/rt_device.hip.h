@@ -1382,17 +1382,19 @@ __device__ __forceinline__ bool slot_pixel(const RenderArgs &ra, int64_t slot, i
  * whole frame runs out of pixels, instead of idling while the longest of 64 fixed pixels finishes. */
 template <bool CNT, bool SPH, bool PLAIN, typename SP>
 __device__ __forceinline__ void render_persistent(const DScene &sc, const DScene &cold, WaveLDS *w, SP sph, const RootRec *roots,
-                                                  const RenderArgs &ra, int k0, int nk, int chunk, double *accum, int *next_slot, int n_slots,
+                                                  const RenderArgs &ra, int k0, int nk, int chunk, double *accum, double *unit_sums, int *next_slot, int n_slots,
                                                   Cnt &cnt) {
     Path q;
     path_begin(q, k0, false); /* finished: no pixel yet */
     const int kend = k0 + nk;
     /* A unit of work is `chunk` consecutive samples of one pixel; the units are numbered chunk by chunk over the frame
      * (n_slots pixel slots each). Short units keep the end of a launch short: once the counter runs out, a wave only has
-     * to finish the units its lanes hold. With more than one unit per pixel the sums are added atomically. */
+     * to finish the units its lanes hold. With more than one unit per pixel a unit's sum is stored in its own place,
+     * unit_sums[unit of the pixel][pixel], and a second kernel adds them to the accumulator in the order of the units,
+     * so the result does not depend on which unit ends first. */
     const int n_chunks = (nk + chunk - 1) / chunk;
     const int n_total = n_slots * n_chunks;
-    int kend_l = kend;
+    int kend_l = kend, unit_c = 0;
     bool have = false, exhausted = false;
     int i = 0, j = 0;
     int cur = 0, end = 0; /* wave-uniform: the part of the last tile request not handed out yet */
@@ -1402,9 +1404,10 @@ __device__ __forceinline__ void render_persistent(const DScene &sc, const DScene
         if (have && q.finished) { /* all samples of this lane's pixel are in q.acc */
             double *px = accum + ((int64_t)i * ra.p.W + j) * 3;
             if (n_chunks > 1) {
-                unsafeAtomicAdd(px, q.acc.x);
-                unsafeAtomicAdd(px + 1, q.acc.y);
-                unsafeAtomicAdd(px + 2, q.acc.z);
+                double *us = unit_sums + (((int64_t)unit_c * ra.p.H + i) * ra.p.W + j) * 3;
+                us[0] = q.acc.x;
+                us[1] = q.acc.y;
+                us[2] = q.acc.z;
             } else {
                 px[0] = px[0] + q.acc.x;
                 px[1] = px[1] + q.acc.y;
@@ -1429,6 +1432,7 @@ __device__ __forceinline__ void render_persistent(const DScene &sc, const DScene
                     const int c = mine / n_slots;
                     const bool live = slot_pixel(ra, mine - c * n_slots, i, j);
                     const int ks = k0 + c * chunk;
+                    unit_c = c;
                     kend_l = ks + chunk < kend ? ks + chunk : kend;
                     path_begin(q, ks, live);
                     have = live; /* a slot outside the rectangle is skipped */

@@ -145,21 +145,26 @@ class TestFullSize:
 
     def test_sample_units_add_up(self, gpu, rta, full):
         """On a frame this large a launch hands out a pixel's samples in units of a few samples (added to the
-        accumulator atomically): 20 samples in one call == the same samples rendered in calls too short to be cut."""
+        accumulator in sample order by a second kernel): 20 samples in one call == the same samples rendered in calls too short
+        to be cut."""
         s, cam, flags = full
         W = 1024
         gpu.accum_clear(W, W)
         gpu.render(cam, rta.make_params(W, W, 20, flags=flags))
         a = gpu.accum_download(W, W)
         gpu.accum_clear(W, W)
-        for k0, n in ((0, 5), (5, 5), (10, 5), (15, 5)):
+        for k0, n in ((0, 8), (8, 8), (16, 4)):  # the units themselves, one call each: the same additions in the same order
             gpu.render(cam, rta.make_params(W, W, n, spp_offset=k0, flags=flags))
         b = gpu.accum_download(W, W)
-        assert np.allclose(a, b, rtol=1e-13, atol=1e-9, equal_nan=True)
+        assert np.array_equal(a, b, equal_nan=True)
+        gpu.accum_clear(W, W)
+        for k0, n in ((0, 5), (5, 5), (10, 5), (15, 5)):
+            gpu.render(cam, rta.make_params(W, W, n, spp_offset=k0, flags=flags))
+        assert np.allclose(a, gpu.accum_download(W, W), rtol=1e-13, atol=1e-9, equal_nan=True)
         assert (a > 0).mean() > 0.9
         gpu.accum_clear(W, W)
         gpu.render(cam, rta.make_params(W, W, 20, flags=flags))
-        assert np.array_equal(a, gpu.accum_download(W, W), equal_nan=True)  # units of one pixel end a whole frame apart: same order
+        assert np.array_equal(a, gpu.accum_download(W, W), equal_nan=True)  # run-to-run identical
 
     def test_pruned_equals_unpruned_and_counted(self, gpu, rta, full):
         s, cam, flags = full
@@ -194,8 +199,26 @@ def test_sample_units_with_the_sphere_tree(gpu, rta, scenes):
     gpu.render(cam, rta.make_params(W, W, 12, flags=flags))
     a = gpu.accum_download(W, W)
     gpu.accum_clear(W, W)
-    for k0 in (0, 4, 8):
-        gpu.render(cam, rta.make_params(W, W, 4, spp_offset=k0, flags=flags))
+    for k0, n in ((0, 8), (8, 4)):
+        gpu.render(cam, rta.make_params(W, W, n, spp_offset=k0, flags=flags))
     b = gpu.accum_download(W, W)
-    assert np.allclose(a, b, rtol=1e-13, atol=1e-9, equal_nan=True)
+    assert np.array_equal(a, b, equal_nan=True)
     assert (a > 0).mean() > 0.9
+
+
+def test_sample_units_on_the_smallest_frame_that_has_them(gpu, rta, scenes):
+    """512 x 512 (the reference's default frame) is two pixels per resident lane on an MI355X: units of 8 samples, the
+    sums equal to those of short calls and identical from run to run"""
+    W = 512
+    s, cam, flags = scenes.sphere_room(W)
+    gpu.upload(s)
+    out = []
+    for _ in range(2):
+        gpu.accum_clear(W, W)
+        gpu.render(cam, rta.make_params(W, W, 24, flags=flags))
+        out.append(gpu.accum_download(W, W))
+    assert np.array_equal(out[0], out[1], equal_nan=True)
+    gpu.accum_clear(W, W)
+    for k0 in (0, 8, 16):
+        gpu.render(cam, rta.make_params(W, W, 8, spp_offset=k0, flags=flags))
+    assert np.array_equal(out[0], gpu.accum_download(W, W), equal_nan=True)
