@@ -211,8 +211,8 @@ int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *scene);
  * the context's stream; rt_sync waits.  The samples of a pixel are summed in
  * order within a work unit (all samples of a launch of up to 64; 8 samples on
  * rects with at least two pixels per resident lane - 262 144 pixels on an
- * MI355X - where the unit sums are added with FP64 atomics: accum must then
- * be ordinary device memory). */
+ * MI355X) and the unit sums are added to accum in sample order, as calls of
+ * one unit each would: results are run-to-run identical. */
 int rt_render(rt_ctx *ctx, const rt_camera *cam, const rt_params *p, double *accum);
 int rt_sync(rt_ctx *ctx);
 /* Zero / read back the context's own accumulator (W*H*3 doubles). */
