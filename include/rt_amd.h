@@ -209,10 +209,10 @@ int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *scene);
  * reference's row index (not flipped).  accum is a DEVICE pointer to
  * W*H*3 doubles, or NULL for the context's own accumulator. Asynchronous on
  * the context's stream; rt_sync waits.  The samples of a pixel are summed in
- * order within a work unit (all samples of a launch of up to 64; 8 samples on
- * rects with at least two pixels per resident lane - 262 144 pixels on an
- * MI355X) and the unit sums are added to accum in sample order, as calls of
- * one unit each would: results are run-to-run identical. */
+ * order within a work unit (8 samples on rects with at least two pixels per
+ * resident lane - 262 144 pixels on an MI355X -, 4, 2 or 1 on smaller ones)
+ * and the unit sums are added to accum in sample order, as calls of one unit
+ * each would: results are run-to-run identical. */
 int rt_render(rt_ctx *ctx, const rt_camera *cam, const rt_params *p, double *accum);
 int rt_sync(rt_ctx *ctx);
 /* Zero / read back the context's own accumulator (W*H*3 doubles). */

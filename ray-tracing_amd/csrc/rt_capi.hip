@@ -801,10 +801,7 @@ static const int kSppPerLaunch = 64;
 #ifndef RT_SPP_PER_UNIT
 #define RT_SPP_PER_UNIT 8
 #endif
-#ifndef RT_UNIT_MIN_PX_PER_LANE
-#define RT_UNIT_MIN_PX_PER_LANE 2
-#endif
-static const int kSppPerUnit = RT_SPP_PER_UNIT; /* samples of one pixel that a lane takes at a time on large frames */
+static const int kSppPerUnit = RT_SPP_PER_UNIT; /* samples of one pixel that a lane takes at a time (fewer on small frames) */
 
 int rt_render(rt_ctx *c, const rt_camera *cam, const rt_params *p, double *accum) {
     if (!c) return RT_E_INVALID;
@@ -819,22 +816,27 @@ int rt_render(rt_ctx *c, const rt_camera *cam, const rt_params *p, double *accum
     const int rw = ra.j1 - ra.j0, rh = ra.i1 - ra.i0;
     const int64_t tiles = (int64_t)((rw + 7) / 8) * ((rh + 7) / 8);
     if (tiles * RT_WAVE > 0x7fffffffLL) return fail(c, RT_E_INVALID, "too many tiles");
-    const unsigned grid = (unsigned)tiles;
     c->last_launches = 0;
     c->timed = false;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     {
         /* persistent waves: as many as stay resident, each pulling 64-pixel tiles */
         const int n_slots = (int)(tiles * RT_WAVE);
-        const unsigned pgrid = grid < (unsigned)(c->n_cus * c->waves_per_cu) ? grid : (unsigned)(c->n_cus * c->waves_per_cu);
+        const int64_t resident = (int64_t)c->n_cus * c->waves_per_cu;
         for (int k = 0; k < p->spp; k += kSppPerLaunch) {
             const int nk = (p->spp - k < kSppPerLaunch) ? (p->spp - k) : kSppPerLaunch;
-            /* Work units of kSppPerUnit samples when the frame has at least RT_UNIT_MIN_PX_PER_LANE pixels per resident lane: the launch then
-             * ends within one short unit per lane instead of one whole pixel. On smaller frames most lanes hold a pixel of
-             * their own for the whole launch anyway. */
+            /* Work units: a lane takes `unit` samples of a pixel at a time, so a launch ends within one short unit per lane
+             * instead of one whole pixel. The unit depends on the rectangle's size only (8 samples from two pixels per
+             * resident lane up, fewer on smaller rectangles, where whole pixels would leave lanes without work), so a
+             * render gives the same sums whichever way its samples are spread over calls that start on unit boundaries. */
+            int unit = kSppPerUnit;
+            {
+                const int64_t lanes = resident * RT_WAVE;
+                while (unit > 1 && (int64_t)n_slots * 8 < lanes * 2 * unit) unit >>= 1;
+            }
             int chunk = nk;
-            const int n_units = (nk + kSppPerUnit - 1) / kSppPerUnit;
-            if (n_units > 1 && (int64_t)n_slots >= RT_UNIT_MIN_PX_PER_LANE * (int64_t)pgrid * RT_WAVE && (int64_t)n_slots * n_units <= 0x7fffffffLL) {
+            const int n_units = (nk + unit - 1) / unit;
+            if (n_units > 1 && (int64_t)n_slots * n_units <= 0x7fffffffLL) {
                 const size_t need = (size_t)n_units * p->W * p->H * 3 * sizeof(double);
                 if (c->unit_sums_bytes < need) { /* kept for the following launches and calls */
                     if (c->unit_sums) (void)hipFree(c->unit_sums);
@@ -843,8 +845,10 @@ int rt_render(rt_ctx *c, const rt_camera *cam, const rt_params *p, double *accum
                     if (hipMalloc((void **)&c->unit_sums, need) == hipSuccess) c->unit_sums_bytes = need;
                     else (void)hipGetLastError(); /* no room: whole pixels as units, slower at the end of the launch */
                 }
-                if (c->unit_sums_bytes >= need) chunk = kSppPerUnit;
+                if (c->unit_sums_bytes >= need) chunk = unit;
             }
+            const int64_t tiles_all = tiles * (chunk < nk ? n_units : 1); /* 64-slot requests that the launch hands out */
+            const unsigned pgrid = (unsigned)(tiles_all < resident ? tiles_all : resident);
             HIPCHK(c, hipMemsetAsync(c->d_next_slot, 0, sizeof(int), c->stream));
             if (c->sc.sph_nodes != nullptr && (p->flags & RT_F_COUNTERS))
                 hipLaunchKernelGGL(rt_render_spheres_kernel<true>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, c->unit_sums, c->d_counters, c->d_next_slot, n_slots);
