@@ -206,9 +206,10 @@ def test_sample_units_with_the_sphere_tree(gpu, rta, scenes):
     assert (a > 0).mean() > 0.9
 
 
-def test_sample_units_on_the_smallest_frame_that_has_them(gpu, rta, scenes):
+def test_sample_units_on_small_frames(gpu, rta, scenes):
     """512 x 512 (the reference's default frame) is two pixels per resident lane on an MI355X: units of 8 samples, the
-    sums equal to those of short calls and identical from run to run"""
+    sums equal to those of calls of one unit each and identical from run to run. 128 x 128: units of one sample, so any
+    split of the samples over calls gives the same bits."""
     W = 512
     s, cam, flags = scenes.sphere_room(W)
     gpu.upload(s)
@@ -222,3 +223,13 @@ def test_sample_units_on_the_smallest_frame_that_has_them(gpu, rta, scenes):
     for k0 in (0, 8, 16):
         gpu.render(cam, rta.make_params(W, W, 8, spp_offset=k0, flags=flags))
     assert np.array_equal(out[0], gpu.accum_download(W, W), equal_nan=True)
+    W = 128
+    s, cam, flags = scenes.sphere_room(W)
+    gpu.upload(s)
+    gpu.accum_clear(W, W)
+    gpu.render(cam, rta.make_params(W, W, 16, flags=flags))
+    a = gpu.accum_download(W, W)
+    gpu.accum_clear(W, W)
+    gpu.render(cam, rta.make_params(W, W, 5, spp_offset=0, flags=flags))
+    gpu.render(cam, rta.make_params(W, W, 11, spp_offset=5, flags=flags))
+    assert np.array_equal(a, gpu.accum_download(W, W), equal_nan=True)
