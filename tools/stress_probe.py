@@ -8,14 +8,15 @@ from oracle import bindings as ob
 n_tris = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 n_sph = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 W = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+spp = int(sys.argv[4]) if len(sys.argv) > 4 else 4  # samples of the timed render
 t0 = time.time(); s, cam, fl = scenes.stress(W=W, n_tris=n_tris, n_spheres=n_sph); t1 = time.time()
 r = rta.Renderer(0); r.upload(s); info = s.flat_info(); t2 = time.time()
 r.accum_clear(W, W)
 r.render(cam, rta.make_params(W, W, 1, flags=fl)); r.sync()
-r.render(cam, rta.make_params(W, W, 4, spp_offset=1, flags=fl)); r.sync()
+r.render(cam, rta.make_params(W, W, spp, spp_offset=1, flags=fl)); r.sync()
 ms = r.last_render_ms()[0]
 out = dict(n_tris=info["n_tris"], n_spheres=info["n_spheres"], MB=round(info["bytes"] / 1e6, 1), build_s=round(t1 - t0, 1), upload_s=round(t2 - t1, 1),
-           Mpaths_s=round(W * W * 4 / ms / 1e3, 2))
+           spp=spp, Mpaths_s=round(W * W * spp / ms / 1e3, 2))
 if n_tris <= 2_000_000:
     orc = ob.OracleScene(scenes.export_objects(s), s.I, s.L)
     ijk = np.array([(i, j, 0) for i in range(100, W, W // 12) for j in range(50, W, W // 12)], np.int32)
