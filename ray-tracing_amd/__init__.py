@@ -49,7 +49,7 @@ class rt_counters(C.Structure):
 
 
 # every symbol include/rt_amd.h and include/rt_amd_host.h declare
-RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_render", "rt_sync", "rt_accum_clear",
+RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_render", "rt_render_static", "rt_sync", "rt_accum_clear",
               "rt_accum_download", "rt_accum_upload", "rt_accum_device_ptr", "rt_resolve", "rt_intersect_rays", "rt_sample_radiance",
               "rt_get_counters", "rt_reset_counters", "rt_last_render_ms", "rt_stream", "rt_version", "rt_build_bvh"]
 RTH_SYMBOLS = ["rth_last_error", "rth_mesh_create", "rth_mesh_destroy", "rth_mesh_read_obj", "rth_mesh_load_texture",
@@ -73,6 +73,7 @@ _sig("rt_create", C.c_int, C.c_int, C.POINTER(_vp))
 _sig("rt_destroy", None, _vp)
 _sig("rt_last_error", C.c_char_p, _vp)
 _sig("rt_render", C.c_int, _vp, C.POINTER(rt_camera), C.POINTER(rt_params), _vp)
+_sig("rt_render_static", C.c_int, _vp, C.POINTER(rt_camera), C.POINTER(rt_params), _vp)
 _sig("rt_sync", C.c_int, _vp)
 _sig("rt_accum_clear", C.c_int, _vp, _i32, _i32)
 _sig("rt_accum_download", C.c_int, _vp, _vp, _i64)
@@ -325,6 +326,10 @@ class Renderer:
     def render(self, cam, params, accum_ptr=None):
         """Adds params.spp samples per pixel into the accumulator (own one if accum_ptr is None)."""
         self._check(lib.rt_render(self._h, C.byref(cam), C.byref(params), accum_ptr))
+
+    def render_static(self, cam, params, accum_ptr=None):
+        """rt_render without any device allocation (static scratch of the library; see rt_render_static in rt_amd.h)."""
+        self._check(lib.rt_render_static(self._h, C.byref(cam), C.byref(params), accum_ptr))
 
     def sync(self):
         self._check(lib.rt_sync(self._h))

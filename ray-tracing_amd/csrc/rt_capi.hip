@@ -24,6 +24,15 @@ using namespace rtd;
 #endif
 #define RT_OCCUPANCY __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_SIMD, RT_WAVES_PER_SIMD)))
 
+/* Scratch of rt_render_static, the entry point that allocates nothing: the tile counter of the persistent waves
+ * (first RT_STATIC_HEADER bytes) and the sums of one launch's work units behind it. One copy per GPU, held from the
+ * moment the library is loaded until the process ends. In host code this name is only a handle for
+ * hipGetSymbolAddress (rt_create asks for the address on its device and keeps it in the context): it is never
+ * passed to a kernel or a copy itself. */
+#define RT_STATIC_HEADER 256
+#define RT_STATIC_UNIT_BYTES (64ull << 20)
+static __device__ __align__(256) unsigned char scratch[RT_STATIC_HEADER + RT_STATIC_UNIT_BYTES];
+
 /* ---------------------------------------------------------------------------------------------
  * kernels
  * ------------------------------------------------------------------------------------------- */
@@ -149,7 +158,7 @@ __global__ void rt_units_add_kernel(double *accum, const double *unit_sums, int 
     const int i = i0 + (int)(px / rw), j = j0 + (int)(px % rw);
     const int64_t at = ((int64_t)i * W + j) * 3 + ch;
     double a = accum[at];
-    for (int u = 0; u < n_units; u++) a = a + unit_sums[(int64_t)u * W * H * 3 + at];
+    for (int u = 0; u < n_units; u++) a = a + unit_sums[(int64_t)u * rw * rh * 3 + t]; /* unit_sums is [unit][rh][rw][3] */
     accum[at] = a;
 }
 
@@ -193,6 +202,7 @@ struct rt_ctx {
     rt_counters *d_counters = nullptr;
     int *d_overflow = nullptr;
     int *d_next_slot = nullptr;
+    unsigned char *static_scratch = nullptr; /* this device's copy of `scratch` (hipGetSymbolAddress at rt_create) */
     int n_cus = 256;
     int waves_per_cu = 8;
     bool probe_prune = true;
@@ -276,6 +286,12 @@ int rt_create(int device, rt_ctx **out) {
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
+    }
+    /* every GPU holds its own copy of the static scratch array at its own address: ask with this device current */
+    if ((e = hipGetSymbolAddress((void **)&c->static_scratch, HIP_SYMBOL(scratch))) != hipSuccess || c->static_scratch == nullptr) {
+        fail(nullptr, RT_E_DEVICE, "rt_create: hipGetSymbolAddress(scratch): %s", hipGetErrorString(e));
+        rt_destroy(c);
+        return RT_E_DEVICE;
     }
     *out = c;
     return RT_OK;
@@ -777,6 +793,7 @@ static int check_render_args(rt_ctx *c, const rt_camera *cam, const rt_params *p
     if (!cam || !p) return fail(c, RT_E_INVALID, "camera or params is NULL");
     if (p->W <= 0 || p->H <= 0 || (int64_t)p->W * p->H > 0x7fffffffLL) return fail(c, RT_E_INVALID, "bad image size %dx%d", p->W, p->H);
     if (p->spp < 0 || p->spp_offset < 0) return fail(c, RT_E_INVALID, "negative spp or spp_offset");
+    if ((int64_t)p->spp_offset + p->spp > 0x7fffffffLL) return fail(c, RT_E_INVALID, "spp_offset + spp exceeds the 31-bit sample index");
     if (p->max_rebond < 0 || p->max_rebond > 1000) return fail(c, RT_E_INVALID, "max_rebond %d out of range", p->max_rebond);
     if (!(p->flags & RT_F_POINT_LIGHT) && !c->light_ok)
         return fail(c, RT_E_INVALID, "objects[0] is not a sphere: the area-light estimator needs the light sphere there (raytracer.cpp:970, :1062)");
@@ -803,7 +820,21 @@ static const int kSppPerLaunch = 64;
 #endif
 static const int kSppPerUnit = RT_SPP_PER_UNIT; /* samples of one pixel that a lane takes at a time (fewer on small frames) */
 
-int rt_render(rt_ctx *c, const rt_camera *cam, const rt_params *p, double *accum) {
+/* Samples of one pixel that a lane takes at a time. The unit depends on the rectangle's size only - 8 samples from
+ * 262 144 pixels up (two pixels per resident lane of an MI355X: 256 CUs x 8 waves x 64 lanes), 4 / 2 / 1 on
+ * rectangles of at least 131 072 / 65 536 / fewer pixels, where whole pixels would leave lanes without work -, not on
+ * the device or the scene, so a render gives the same sums on every GPU and whichever way its samples are spread over
+ * calls that start on unit boundaries. */
+#define RT_UNIT_LANES 131072
+static int unit_for(int n_slots) {
+    int unit = kSppPerUnit;
+    while (unit > 1 && (int64_t)n_slots * 8 < (int64_t)RT_UNIT_LANES * 2 * unit) unit >>= 1;
+    return unit;
+}
+
+/* rt_render and rt_render_static: the same launches. use_static: the tile counter and the unit sums live in this
+ * device's copy of the static scratch array and nothing is allocated. */
+static int render_impl(rt_ctx *c, const rt_camera *cam, const rt_params *p, double *accum, bool use_static) {
     if (!c) return RT_E_INVALID;
     RenderArgs ra;
     int rc = check_render_args(c, cam, p, &ra);
@@ -815,65 +846,83 @@ int rt_render(rt_ctx *c, const rt_camera *cam, const rt_params *p, double *accum
     HIPCHK(c, hipSetDevice(c->device));
     const int rw = ra.j1 - ra.j0, rh = ra.i1 - ra.i0;
     const int64_t tiles = (int64_t)((rw + 7) / 8) * ((rh + 7) / 8);
-    if (tiles * RT_WAVE > 0x7fffffffLL) return fail(c, RT_E_INVALID, "too many tiles");
+    const int64_t resident = (int64_t)c->n_cus * c->waves_per_cu;
+    /* the slot counter is a 32-bit int that every resident wave may still bump by 64 once after the slots have run out */
+    const int64_t slot_limit = 0x7fffffffLL - 64 * 64 * resident;
+    if (tiles * RT_WAVE > slot_limit) return fail(c, RT_E_INVALID, "too many tiles");
+    const int n_slots = (int)(tiles * RT_WAVE);
+    const int unit = unit_for(n_slots);
+    const size_t unit_bytes = (size_t)rw * rh * 3 * sizeof(double); /* sums of one unit of every pixel of the rectangle */
+    int *next_slot = c->d_next_slot;
+    double *unit_sums = c->unit_sums;
+    if (use_static) {
+        const int nk_max = p->spp < kSppPerLaunch ? p->spp : kSppPerLaunch;
+        const int n_units_max = (nk_max + unit - 1) / unit;
+        if (n_units_max > 1 && (uint64_t)n_units_max * unit_bytes > RT_STATIC_UNIT_BYTES)
+            return fail(c, RT_E_INVALID,
+                        "rt_render_static: %d work units of %d x %d pixels need %llu bytes of scratch, the static array holds %llu: render a smaller "
+                        "rect or at most %d samples per call (or use rt_render)",
+                        n_units_max, rw, rh, (unsigned long long)((uint64_t)n_units_max * unit_bytes), (unsigned long long)RT_STATIC_UNIT_BYTES, unit);
+        next_slot = reinterpret_cast<int *>(c->static_scratch);
+        unit_sums = reinterpret_cast<double *>(c->static_scratch + RT_STATIC_HEADER);
+    }
     c->last_launches = 0;
     c->timed = false;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    {
-        /* persistent waves: as many as stay resident, each pulling 64-pixel tiles */
-        const int n_slots = (int)(tiles * RT_WAVE);
-        const int64_t resident = (int64_t)c->n_cus * c->waves_per_cu;
-        for (int k = 0; k < p->spp; k += kSppPerLaunch) {
-            const int nk = (p->spp - k < kSppPerLaunch) ? (p->spp - k) : kSppPerLaunch;
-            /* Work units: a lane takes `unit` samples of a pixel at a time, so a launch ends within one short unit per lane
-             * instead of one whole pixel. The unit depends on the rectangle's size only (8 samples from two pixels per
-             * resident lane up, fewer on smaller rectangles, where whole pixels would leave lanes without work), so a
-             * render gives the same sums whichever way its samples are spread over calls that start on unit boundaries. */
-            int unit = kSppPerUnit;
-            {
-                const int64_t lanes = resident * RT_WAVE;
-                while (unit > 1 && (int64_t)n_slots * 8 < lanes * 2 * unit) unit >>= 1;
+    /* persistent waves: as many as stay resident, each pulling 64-pixel tiles */
+    for (int k = 0; k < p->spp; k += kSppPerLaunch) {
+        const int nk = (p->spp - k < kSppPerLaunch) ? (p->spp - k) : kSppPerLaunch;
+        /* Work units: a lane takes `unit` samples of a pixel at a time, so a launch ends within one short unit per lane
+         * instead of one whole pixel. */
+        int chunk = nk;
+        const int n_units = (nk + unit - 1) / unit;
+        if (n_units > 1 && (int64_t)n_slots * n_units > slot_limit) {
+            /* frames of tens of megapixels: whole pixels as units */
+        } else if (n_units > 1 && use_static) {
+            chunk = unit; /* fits: checked above */
+        } else if (n_units > 1) {
+            const size_t need = (size_t)n_units * unit_bytes;
+            if (c->unit_sums_bytes < need) { /* kept for the following launches and calls */
+                HIPCHK(c, hipStreamSynchronize(c->stream)); /* earlier launches may still use the old buffer */
+                if (c->unit_sums) (void)hipFree(c->unit_sums);
+                c->unit_sums = nullptr;
+                c->unit_sums_bytes = 0;
+                if (hipMalloc((void **)&c->unit_sums, need) == hipSuccess) c->unit_sums_bytes = need;
+                else (void)hipGetLastError(); /* no room: whole pixels as units, slower at the end of the launch */
             }
-            int chunk = nk;
-            const int n_units = (nk + unit - 1) / unit;
-            if (n_units > 1 && (int64_t)n_slots * n_units <= 0x7fffffffLL) {
-                const size_t need = (size_t)n_units * p->W * p->H * 3 * sizeof(double);
-                if (c->unit_sums_bytes < need) { /* kept for the following launches and calls */
-                    if (c->unit_sums) (void)hipFree(c->unit_sums);
-                    c->unit_sums = nullptr;
-                    c->unit_sums_bytes = 0;
-                    if (hipMalloc((void **)&c->unit_sums, need) == hipSuccess) c->unit_sums_bytes = need;
-                    else (void)hipGetLastError(); /* no room: whole pixels as units, slower at the end of the launch */
-                }
-                if (c->unit_sums_bytes >= need) chunk = unit;
-            }
-            const int64_t tiles_all = tiles * (chunk < nk ? n_units : 1); /* 64-slot requests that the launch hands out */
-            const unsigned pgrid = (unsigned)(tiles_all < resident ? tiles_all : resident);
-            HIPCHK(c, hipMemsetAsync(c->d_next_slot, 0, sizeof(int), c->stream));
-            if (c->sc.sph_nodes != nullptr && (p->flags & RT_F_COUNTERS))
-                hipLaunchKernelGGL(rt_render_spheres_kernel<true>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, c->unit_sums, c->d_counters, c->d_next_slot, n_slots);
-            else if (c->sc.sph_nodes != nullptr)
-                hipLaunchKernelGGL(rt_render_spheres_kernel<false>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, c->unit_sums, c->d_counters, c->d_next_slot, n_slots);
-            else if (p->flags == 0)
-                hipLaunchKernelGGL((rt_render_kernel<false, true>), dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, c->unit_sums, c->d_counters, c->d_next_slot, n_slots);
-            else if (p->flags & RT_F_COUNTERS)
-                hipLaunchKernelGGL(rt_render_kernel<true>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, c->unit_sums, c->d_counters, c->d_next_slot, n_slots);
-            else
-                hipLaunchKernelGGL(rt_render_kernel<false>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, c->unit_sums, c->d_counters, c->d_next_slot, n_slots);
-            HIPCHK(c, hipGetLastError());
-            if (chunk < nk) {
-                const int64_t nthr = (int64_t)rw * rh * 3;
-                hipLaunchKernelGGL(rt_units_add_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, c->stream, accum, c->unit_sums, n_units, p->W, p->H,
-                                   ra.j0, ra.i0, rw, rh);
-                HIPCHK(c, hipGetLastError());
-            }
-            c->last_launches++;
+            unit_sums = c->unit_sums;
+            if (c->unit_sums_bytes >= need) chunk = unit;
         }
+        const int64_t tiles_all = tiles * (chunk < nk ? n_units : 1); /* 64-slot requests that the launch hands out */
+        const unsigned pgrid = (unsigned)(tiles_all < resident ? tiles_all : resident);
+        HIPCHK(c, hipMemsetAsync(next_slot, 0, sizeof(int), c->stream));
+        if (c->sc.sph_nodes != nullptr && (p->flags & RT_F_COUNTERS))
+            hipLaunchKernelGGL(rt_render_spheres_kernel<true>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, unit_sums, c->d_counters, next_slot, n_slots);
+        else if (c->sc.sph_nodes != nullptr)
+            hipLaunchKernelGGL(rt_render_spheres_kernel<false>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, unit_sums, c->d_counters, next_slot, n_slots);
+        else if (p->flags == 0)
+            hipLaunchKernelGGL((rt_render_kernel<false, true>), dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, unit_sums, c->d_counters, next_slot, n_slots);
+        else if (p->flags & RT_F_COUNTERS)
+            hipLaunchKernelGGL(rt_render_kernel<true>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, unit_sums, c->d_counters, next_slot, n_slots);
+        else
+            hipLaunchKernelGGL(rt_render_kernel<false>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, unit_sums, c->d_counters, next_slot, n_slots);
+        HIPCHK(c, hipGetLastError());
+        if (chunk < nk) {
+            const int64_t nthr = (int64_t)rw * rh * 3;
+            hipLaunchKernelGGL(rt_units_add_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, c->stream, accum, unit_sums, n_units, p->W, p->H,
+                               ra.j0, ra.i0, rw, rh);
+            HIPCHK(c, hipGetLastError());
+        }
+        c->last_launches++;
     }
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->timed = true;
     return RT_OK;
 }
+
+int rt_render(rt_ctx *c, const rt_camera *cam, const rt_params *p, double *accum) { return render_impl(c, cam, p, accum, false); }
+
+int rt_render_static(rt_ctx *c, const rt_camera *cam, const rt_params *p, double *accum) { return render_impl(c, cam, p, accum, true); }
 
 int rt_sync(rt_ctx *c) {
     if (!c) return RT_E_INVALID;

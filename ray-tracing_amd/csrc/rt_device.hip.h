@@ -1404,7 +1404,8 @@ __device__ __forceinline__ void render_persistent(const DScene &sc, const DScene
         if (have && q.finished) { /* all samples of this lane's pixel are in q.acc */
             double *px = accum + ((int64_t)i * ra.p.W + j) * 3;
             if (n_chunks > 1) {
-                double *us = unit_sums + (((int64_t)unit_c * ra.p.H + i) * ra.p.W + j) * 3;
+                /* [unit][row of the rectangle][column of the rectangle][3] */
+                double *us = unit_sums + (((int64_t)unit_c * (ra.i1 - ra.i0) + (i - ra.i0)) * (ra.j1 - ra.j0) + (j - ra.j0)) * 3;
                 us[0] = q.acc.x;
                 us[1] = q.acc.y;
                 us[2] = q.acc.z;
