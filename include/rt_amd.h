@@ -259,6 +259,26 @@ int rt_intersect_rays(rt_ctx *ctx, const double *rays, int64_t n, int32_t *obj_i
 int rt_sample_radiance(rt_ctx *ctx, const rt_camera *cam, const rt_params *p, const int32_t *ijk,
                        int64_t n, double *out);
 
+/* rt_sample_radiance plus the path each sample took, for explaining a difference between two implementations bounce by
+ * bounce. trace (HOST, n * RT_TRACE_LEN * 4 int32, may be NULL): entry d of a sample describes the Scene::intersect call
+ * of Scene::getColor at recursion depth `rebond` = d (raytracer.cpp:960):
+ *   [0] objectId of the hit or -1 (miss),  [1] orig_id of the hit triangle or -1,
+ *   [2] random draws the path had used before that call,
+ *   [3] what getColor did with the hit: one of RT_TRACE_*.
+ * Entries the path never reached hold {-1, -1, 0, RT_TRACE_UNUSED}. */
+#define RT_TRACE_LEN 12               /* rebond 0 .. 11: the call at depth 11 is made and discarded (raytracer.cpp:960-963) */
+#define RT_TRACE_UNUSED 0
+#define RT_TRACE_NONE 1               /* miss, or the depth limit: nothing further */
+#define RT_TRACE_LIGHT 2              /* objects[0] (raytracer.cpp:966-973) */
+#define RT_TRACE_MIRROR 3             /* :974-979 */
+#define RT_TRACE_TOTAL_REFLECTION 4   /* :994-999 */
+#define RT_TRACE_REFLECT 5            /* the Fresnel coin chose reflection (:1008-1013) */
+#define RT_TRACE_REFRACT 6            /* it chose refraction (:1015-1020) */
+#define RT_TRACE_DIFFUSE_LIT 7        /* diffuse vertex, shadow ray not blocked (:1073-1083) */
+#define RT_TRACE_DIFFUSE_SHADOWED 8   /* diffuse vertex, shadow ray blocked */
+int rt_sample_trace(rt_ctx *ctx, const rt_camera *cam, const rt_params *p, const int32_t *ijk, int64_t n, double *out,
+                    int32_t *trace);
+
 /* Counters accumulated by renders with RT_F_COUNTERS since the last reset. */
 int rt_get_counters(rt_ctx *ctx, rt_counters *out);
 int rt_reset_counters(rt_ctx *ctx);

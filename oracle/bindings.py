@@ -48,6 +48,10 @@ def _load_oracle():
     lib.orc_mesh_bvh_dump.argtypes = [_vp, C.c_int, _vp, _vp, _i64]
     lib.orc_intersect_rays.argtypes = [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.orc_sample_radiance.argtypes = [_vp, _vp, _vp, _vp, _i64, _vp]
+    lib.orc_sample_trace.argtypes = [_vp, _vp, _vp, _vp, _i64, _vp, _vp]
+    lib.orc_set_math.argtypes = [C.c_int]
+    lib.orc_math_sincos.argtypes = [_vp, _i64, _vp, _vp]
+    lib.orc_math_log.argtypes = [_vp, _i64, _vp]
     lib.orc_render.argtypes = [_vp, _vp, _vp, _vp, C.c_int, _vp]
     lib.orc_resolve.argtypes = [_vp, _i32, _i32, _dbl, _vp]
     lib.orc_rng_key.restype = C.c_uint64
@@ -101,10 +105,18 @@ def _hit_arrays(n):
     return (np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n), np.empty((n, 6)), np.empty((n, 3)))
 
 
-class OracleScene:
-    """The CPU restatement (oracle/ref_cpu.cpp) on an exported object list."""
+MATH_MODES = {"libm": 0, "portable": 1}
 
-    def __init__(self, objects, I, L):
+
+class OracleScene:
+    """The CPU restatement (oracle/ref_cpu.cpp) on an exported object list.
+
+    math: which cos / sin / log the sampling code uses - "libm" (the host's, as the reference: the mode that is
+    bit-identical to the real reference) or "portable" (ray-tracing_amd/csrc/rt_math.h, the functions the GPU computes
+    with: the mode the GPU is compared against sample by sample). Closest-hit queries do not depend on it."""
+
+    def __init__(self, objects, I, L, math="libm"):
+        self.math = math
         self._keep = []
         self._h = orc.orc_scene_create(float(I), _d3(L))
         self.mesh_ids = []
@@ -138,15 +150,22 @@ class OracleScene:
                                C.byref(counters) if counters is not None else None)
         return dict(obj=obj, tri=tri, t=t, P=PN[:, :3].copy(), N=PN[:, 3:].copy(), albedo=alb)
 
-    def sample_radiance(self, cam, params, ijk):
+    def sample_radiance(self, cam, params, ijk, math=None):
+        return self.sample_trace(cam, params, ijk, math, want_trace=False)[0]
+
+    def sample_trace(self, cam, params, ijk, math=None, want_trace=True):
+        """radiance (n, 3) and the path of every sample (n, 12, 4), coded as rt_sample_trace of rt_amd.h"""
         ijk = np.ascontiguousarray(ijk, np.int32).reshape(-1, 3)
         out = np.empty((len(ijk), 3))
-        orc.orc_sample_radiance(self._h, C.byref(cam), C.byref(params), _ptr(ijk), len(ijk), _ptr(out))
-        return out
+        trace = np.empty((len(ijk), 12, 4), np.int32) if want_trace else None
+        orc.orc_set_math(MATH_MODES[math or self.math])
+        orc.orc_sample_trace(self._h, C.byref(cam), C.byref(params), _ptr(ijk), len(ijk), _ptr(out), _ptr(trace))
+        return out, trace
 
-    def render(self, cam, params, accum=None, n_threads=0, counters=None):
+    def render(self, cam, params, accum=None, n_threads=0, counters=None, math=None):
         if accum is None:
             accum = np.zeros((params.H, params.W, 3))
+        orc.orc_set_math(MATH_MODES[math or self.math])
         orc.orc_render(self._h, C.byref(cam), C.byref(params), _ptr(accum), int(n_threads),
                        C.byref(counters) if counters is not None else None)
         return accum
@@ -163,6 +182,43 @@ class OracleScene:
         k = orc.orc_mesh_bvh_dump(self._h, object_id, _ptr(boxes), _ptr(dfl), n_nodes)
         assert k == n_nodes, (k, n_nodes)
         return boxes, dfl
+
+
+def portable_sincos(x):
+    x = np.ascontiguousarray(x, np.float64)
+    s, c = np.empty_like(x), np.empty_like(x)
+    orc.orc_math_sincos(_ptr(x), x.size, _ptr(s), _ptr(c))
+    return s, c
+
+
+def portable_log(x):
+    x = np.ascontiguousarray(x, np.float64)
+    out = np.empty_like(x)
+    orc.orc_math_log(_ptr(x), x.size, _ptr(out))
+    return out
+
+
+def explain_divergence(trace_a, trace_b, jittered=True):
+    """Why two implementations' radiance of ONE sample may differ by more than rounding: compares their path traces
+    (12 x 4: object id, triangle id, draws used, RT_TRACE_* code per recursion depth) and returns a reason string, or
+    None if the difference is NOT explained. Explained means: the paths agree entry by entry up to some depth d, at
+    which they hit a different object / triangle (a ray that grazes a silhouette), or take a different branch at the
+    same hit (the Fresnel coin's threshold 100 R, or a shadow ray grazing an occluder), AND the ray that reached depth d
+    had a direction that depends on cos / sin / log - the camera jitter (every path when `jittered`) or a diffuse
+    vertex before d. Identical traces explain nothing."""
+    for d in range(12):
+        a, b = trace_a[d], trace_b[d]
+        if np.array_equal(a, b):
+            continue
+        transcendental = jittered or any(trace_a[e][3] in (7, 8) for e in range(d))
+        if not transcendental:
+            return None
+        if a[0] != b[0] or a[1] != b[1]:
+            return "depth %d: hit object/triangle %d/%d vs %d/%d (silhouette)" % (d, a[0], a[1], b[0], b[1])
+        if a[3] != b[3]:
+            return "depth %d: same hit %d/%d, branch %d vs %d (Fresnel coin or shadow ray at a limit)" % (d, a[0], a[1], a[3], b[3])
+        return None  # same hit, same branch, another draw count: the streams themselves disagree - never legitimate
+    return None
 
 
 def resolve(accum, spp_total):

@@ -15,6 +15,7 @@
  * random_cos calls of a diffuse vertex (:1061, :1086).
  */
 #include "ref_cpu.h"
+#include "../ray-tracing_amd/csrc/rt_math.h" /* the portable sin / cos / log that the GPU uses (orc_set_math) */
 
 #include <math.h>
 #include <stdlib.h>
@@ -29,6 +30,16 @@
 namespace {
 
 const double kPi = 3.14159265358979323846; /* raytracer.cpp:15 */
+
+/* Which cos / sin / log the sampling code calls: 0 = the host's libm, as the reference does (this is the mode that is
+ * bit-identical to the reference's own classes); 1 = rt_math.h, the functions the GPU uses (this is the mode the GPU
+ * is compared against: then both sides walk the same paths). Set by orc_set_math before a call, read-only during it. */
+int g_portable_math = 0;
+inline void sin_cos(double x, double *sn, double *cs) {
+    if (g_portable_math) rtm::sincos_0_7(x, sn, cs);
+    else { *cs = cos(x); *sn = sin(x); }
+}
+inline double log_of(double x) { return g_portable_math ? rtm::log_pos(x) : log(x); }
 
 /* ---- 3-vector algebra: raytracer.cpp:29-110 -------------------------------------------- */
 struct V3 {
@@ -329,8 +340,10 @@ bool scene_hit(const orc_scene &sc, const Ray &r, SceneHit &h, Cnt *cnt) {
 V3 random_cos(Rng &g, V3 N) {
     double u1 = g.uniform();
     double u2 = g.uniform();
-    double x = cos(2 * kPi * u1) * sqrt(1 - u2);
-    double y = sin(2 * kPi * u1) * sqrt(1 - u2);
+    double sn, cs;
+    sin_cos(2 * kPi * u1, &sn, &cs);
+    double x = cs * sqrt(1 - u2);
+    double y = sn * sqrt(1 - u2);
     double z = sqrt(u2);
     V3 T1;
     if (N.x < N.y && N.x < N.z) T1 = mk(0, N.z, -N.y);
@@ -345,7 +358,19 @@ struct Ctx {
     const orc_scene *sc;
     const rt_params *p;
     Cnt *cnt;
+    int32_t *trace; /* RT_TRACE_LEN entries of 4 ints for the current sample (see rt_sample_trace in rt_amd.h), or NULL */
 };
+inline void trace_hit(const Ctx &cx, int rebond, bool inter, const SceneHit &h, const Rng &g) {
+    if (!cx.trace || rebond >= RT_TRACE_LEN) return;
+    int32_t *e = cx.trace + 4 * rebond;
+    e[0] = inter ? h.objectId : -1;
+    e[1] = inter ? h.tri : -1;
+    e[2] = (int32_t)g.n;
+    e[3] = RT_TRACE_NONE;
+}
+inline void trace_branch(const Ctx &cx, int rebond, int code) {
+    if (cx.trace && rebond < RT_TRACE_LEN) cx.trace[4 * rebond + 3] = code;
+}
 
 /* Scene::getColor, raytracer.cpp:953-1093 (+ the commented variants behind flags) */
 V3 get_color(const Ctx &cx, Rng &g, const Ray &r, int rebond, bool lastDiffuse) {
@@ -355,10 +380,12 @@ V3 get_color(const Ctx &cx, Rng &g, const Ray &r, int rebond, bool lastDiffuse) 
     SceneHit h;
     bool inter = scene_hit(sc, r, h, cx.cnt); /* before the depth test, :960-963 */
     V3 color = mk(0, 0, 0);
+    trace_hit(cx, rebond, inter, h, g);
     if (rebond > cx.p->max_rebond) return mk(0., 0., 0.);
     if (!inter) return color;
     const V3 P = h.P, N = h.N, albedo = h.albedo;
     if (h.objectId == 0 && !(fl & RT_F_POINT_LIGHT)) { /* :966-973 */
+        trace_branch(cx, rebond, RT_TRACE_LIGHT);
         if (rebond == 0 || !lastDiffuse) {
             double Rl = sc.objects[0].R;
             return divs(mk(sc.I, sc.I, sc.I), 4 * kPi * kPi * sqr(Rl));
@@ -367,6 +394,7 @@ V3 get_color(const Ctx &cx, Rng &g, const Ray &r, int rebond, bool lastDiffuse) 
     }
     if (h.mirror) { /* :974-979 */
         if (cx.cnt) cx.cnt->specular++;
+        trace_branch(cx, rebond, RT_TRACE_MIRROR);
         V3 reflectedDir = sub(r.u, smul(2 * dot(r.u, N), N));
         Ray rr{add(P, smul(epsilon, N)), reflectedDir};
         return get_color(cx, g, rr, rebond + 1, false);
@@ -381,6 +409,7 @@ V3 get_color(const Ctx &cx, Rng &g, const Ray &r, int rebond, bool lastDiffuse) 
         }
         double rad = 1 - sqr(n1 / n2) * (1 - sqr(dot(r.u, N2)));
         if (rad < 0) {
+            trace_branch(cx, rebond, RT_TRACE_TOTAL_REFLECTION);
             V3 reflectedDir = sub(r.u, smul(2 * dot(r.u, N), N));
             Ray rr{add(P, smul(epsilon, N)), reflectedDir};
             return get_color(cx, g, rr, rebond + 1, false);
@@ -392,6 +421,7 @@ V3 get_color(const Ctx &cx, Rng &g, const Ray &r, int rebond, bool lastDiffuse) 
             double random = g.rand31() % 100;
             reflect = (random <= 100 * R);
         }
+        trace_branch(cx, rebond, reflect ? RT_TRACE_REFLECT : RT_TRACE_REFRACT);
         if (reflect) {
             V3 reflectedDir = sub(r.u, smul(2 * dot(r.u, N), N));
             Ray rr{add(P, smul(epsilon, N)), reflectedDir}; /* N, not N2: :1011 */
@@ -411,6 +441,7 @@ V3 get_color(const Ctx &cx, Rng &g, const Ray &r, int rebond, bool lastDiffuse) 
         SceneHit sh;
         Ray shadowRay{add(P, smul(0.00001, N)), divs(PL, d)};
         bool shadowInter = scene_hit(sc, shadowRay, sh, cx.cnt);
+        trace_branch(cx, rebond, (shadowInter && sh.t < d) ? RT_TRACE_DIFFUSE_SHADOWED : RT_TRACE_DIFFUSE_LIT);
         if (shadowInter && sh.t < d) {
             color = mk(0., 0., 0.);
         } else {
@@ -428,6 +459,7 @@ V3 get_color(const Ctx &cx, Rng &g, const Ray &r, int rebond, bool lastDiffuse) 
         SceneHit sh;
         Ray shadowRay{add(P, smul(0.00001, N)), Pxprime};
         bool shadowInter = scene_hit(sc, shadowRay, sh, cx.cnt);
+        trace_branch(cx, rebond, (shadowInter && sh.t < d - cx.p->shadow_bias) ? RT_TRACE_DIFFUSE_SHADOWED : RT_TRACE_DIFFUSE_LIT);
         if (shadowInter && sh.t < d - cx.p->shadow_bias) {
             color = mk(0., 0., 0.);
         } else {
@@ -465,11 +497,14 @@ V3 sample_radiance(const Ctx &cx, const rt_camera &cam, int i, int j, int k) {
         return get_color(cx, g, r, 0, false);
     }
     double u1 = g.uniform(), u2 = g.uniform();
-    double x1 = cam.aa_sigma * cos(2 * kPi * u1) * sqrt(-2 * log(u2)),
-           x2 = cam.aa_sigma * sin(2 * kPi * u1) * sqrt(-2 * log(u2));
+    double s1, c1, s3, c3;
+    sin_cos(2 * kPi * u1, &s1, &c1);
+    double x1 = cam.aa_sigma * c1 * sqrt(-2 * log_of(u2)),
+           x2 = cam.aa_sigma * s1 * sqrt(-2 * log_of(u2));
     double u3 = g.uniform(), u4 = g.uniform();
-    double x3 = cam.dof_sigma * cos(2 * kPi * u3) * sqrt(-2 * log(u4)),
-           x4 = cam.dof_sigma * sin(2 * kPi * u3) * sqrt(-2 * log(u4));
+    sin_cos(2 * kPi * u3, &s3, &c3);
+    double x3 = cam.dof_sigma * c3 * sqrt(-2 * log_of(u4)),
+           x4 = cam.dof_sigma * s3 * sqrt(-2 * log_of(u4));
     V3 u = mk(j - p.W / 2 + x2 + 0.5, i - p.H / 2 + x1 + 0.5, cam.zdist);
     u = unit(u);
     u = add(add(smul(u.x, right), smul(u.y, up)), smul(u.z, view));
@@ -621,6 +656,8 @@ void orc_intersect_rays(const orc_scene *s, const double *rays, int64_t n, int32
                         rt_counters *counters) {
     Cnt c;
     memset(&c, 0, sizeof c);
+    /* rays are independent: all host threads when no counters are asked for (the counters are one shared set) */
+#pragma omp parallel for schedule(dynamic, 256) if (counters == NULL)
     for (int64_t q = 0; q < n; q++) {
         Ray r{mk(rays[6 * q], rays[6 * q + 1], rays[6 * q + 2]), mk(rays[6 * q + 3], rays[6 * q + 4], rays[6 * q + 5])};
         SceneHit h;
@@ -644,11 +681,32 @@ void orc_intersect_rays(const orc_scene *s, const double *rays, int64_t n, int32
 
 void orc_sample_radiance(const orc_scene *s, const rt_camera *cam, const rt_params *p,
                          const int32_t *ijk, int64_t n, double *out) {
-    Ctx cx{s, p, NULL};
+    orc_sample_trace(s, cam, p, ijk, n, out, NULL);
+}
+
+void orc_sample_trace(const orc_scene *s, const rt_camera *cam, const rt_params *p, const int32_t *ijk,
+                      int64_t n, double *out, int32_t *trace) {
+#pragma omp parallel for schedule(dynamic, 64)
     for (int64_t q = 0; q < n; q++) {
+        Ctx cx{s, p, NULL, trace ? trace + q * 4 * RT_TRACE_LEN : NULL};
+        if (cx.trace)
+            for (int e = 0; e < RT_TRACE_LEN; e++) {
+                cx.trace[4 * e] = cx.trace[4 * e + 1] = -1;
+                cx.trace[4 * e + 2] = 0;
+                cx.trace[4 * e + 3] = RT_TRACE_UNUSED;
+            }
         V3 c = sample_radiance(cx, *cam, ijk[3 * q], ijk[3 * q + 1], ijk[3 * q + 2]);
         out[3 * q] = c.x; out[3 * q + 1] = c.y; out[3 * q + 2] = c.z;
     }
+}
+
+void orc_set_math(int portable) { g_portable_math = portable ? 1 : 0; }
+int orc_get_math(void) { return g_portable_math; }
+void orc_math_sincos(const double *x, int64_t n, double *sn, double *cs) {
+    for (int64_t i = 0; i < n; i++) rtm::sincos_0_7(x[i], sn + i, cs + i);
+}
+void orc_math_log(const double *x, int64_t n, double *out) {
+    for (int64_t i = 0; i < n; i++) out[i] = rtm::log_pos(x[i]);
 }
 
 void orc_render(const orc_scene *s, const rt_camera *cam, const rt_params *p, double *accum,
@@ -667,7 +725,7 @@ void orc_render(const orc_scene *s, const rt_camera *cam, const rt_params *p, do
     {
         Cnt c;
         memset(&c, 0, sizeof c);
-        Ctx cx{s, p, counters ? &c : NULL};
+        Ctx cx{s, p, counters ? &c : NULL, NULL};
 #pragma omp for schedule(dynamic, 1)
         for (int i = i0; i < i1; i++) {
             for (int j = j0; j < j1; j++) {

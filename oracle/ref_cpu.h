@@ -55,6 +55,19 @@ void orc_intersect_rays(const orc_scene *s, const double *rays, int64_t n, int32
 void orc_sample_radiance(const orc_scene *s, const rt_camera *cam, const rt_params *p,
                          const int32_t *ijk, int64_t n, double *out);
 
+/* the same with the path each sample took: trace = n * RT_TRACE_LEN * 4 ints, laid out and coded as rt_sample_trace of
+ * rt_amd.h describes (may be NULL) */
+void orc_sample_trace(const orc_scene *s, const rt_camera *cam, const rt_params *p, const int32_t *ijk,
+                      int64_t n, double *out, int32_t *trace);
+
+/* cos / sin / log of the sampling code: 0 = host libm (as the reference; the default), 1 = ray-tracing_amd/csrc/rt_math.h
+ * (what the GPU computes with). Process-wide; set between calls. */
+void orc_set_math(int portable);
+int orc_get_math(void);
+/* rt_math.h's functions themselves, for accuracy tests */
+void orc_math_sincos(const double *x, int64_t n, double *sn, double *cs);
+void orc_math_log(const double *x, int64_t n, double *out);
+
 /* pixel loop: adds p->spp samples per pixel of p->rect into accum
  * (W*H*3 doubles, reference row order). n_threads <= 0: all OpenMP threads. */
 void orc_render(const orc_scene *s, const rt_camera *cam, const rt_params *p, double *accum,

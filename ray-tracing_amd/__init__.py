@@ -27,6 +27,9 @@ lib = C.CDLL(LIB_PATH)
 # --- PODs of include/rt_amd.h --------------------------------------------------------------------
 RT_MAT_MIRROR, RT_MAT_TRANSPARENT = 1, 2
 RT_F_POINT_LIGHT, RT_F_NO_INDIRECT, RT_F_NO_FRESNEL, RT_F_NO_JITTER, RT_F_COUNTERS, RT_F_NO_PRUNE = 1, 2, 4, 8, 16, 32
+RT_TRACE_LEN = 12
+(RT_TRACE_UNUSED, RT_TRACE_NONE, RT_TRACE_LIGHT, RT_TRACE_MIRROR, RT_TRACE_TOTAL_REFLECTION, RT_TRACE_REFLECT, RT_TRACE_REFRACT,
+ RT_TRACE_DIFFUSE_LIT, RT_TRACE_DIFFUSE_SHADOWED) = range(9)
 
 
 class rt_camera(C.Structure):
@@ -50,7 +53,7 @@ class rt_counters(C.Structure):
 
 # every symbol include/rt_amd.h and include/rt_amd_host.h declare
 RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_render", "rt_render_static", "rt_sync", "rt_accum_clear",
-              "rt_accum_download", "rt_accum_upload", "rt_accum_device_ptr", "rt_resolve", "rt_intersect_rays", "rt_sample_radiance",
+              "rt_accum_download", "rt_accum_upload", "rt_accum_device_ptr", "rt_resolve", "rt_intersect_rays", "rt_sample_radiance", "rt_sample_trace",
               "rt_get_counters", "rt_reset_counters", "rt_last_render_ms", "rt_stream", "rt_version", "rt_build_bvh"]
 RTH_SYMBOLS = ["rth_last_error", "rth_mesh_create", "rth_mesh_destroy", "rth_mesh_read_obj", "rth_mesh_load_texture",
                "rth_mesh_add_texture", "rth_mesh_set_raw", "rth_mesh_op", "rth_mesh_build_bvh", "rth_mesh_build_bvh_device", "rth_mesh_sizes",
@@ -82,6 +85,7 @@ _sig("rt_accum_device_ptr", _vp, _vp)
 _sig("rt_resolve", C.c_int, _vp, _vp, _i32, _i32, _dbl, _vp)
 _sig("rt_intersect_rays", C.c_int, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp)
 _sig("rt_sample_radiance", C.c_int, _vp, C.POINTER(rt_camera), C.POINTER(rt_params), _vp, _i64, _vp)
+_sig("rt_sample_trace", C.c_int, _vp, C.POINTER(rt_camera), C.POINTER(rt_params), _vp, _i64, _vp, _vp)
 _sig("rt_get_counters", C.c_int, _vp, C.POINTER(rt_counters))
 _sig("rt_reset_counters", C.c_int, _vp)
 _sig("rt_last_render_ms", C.c_int, _vp, _pd, C.POINTER(_i32))
@@ -364,6 +368,14 @@ class Renderer:
         out = np.empty((len(ijk), 3))
         self._check(lib.rt_sample_radiance(self._h, C.byref(cam), C.byref(params), _ptr(ijk), len(ijk), _ptr(out)))
         return out
+
+    def sample_trace(self, cam, params, ijk):
+        """radiance (n, 3) and the path of every sample (n, RT_TRACE_LEN, 4): object id, triangle id, draws used, RT_TRACE_* code"""
+        ijk = np.ascontiguousarray(ijk, np.int32).reshape(-1, 3)
+        out = np.empty((len(ijk), 3))
+        trace = np.empty((len(ijk), RT_TRACE_LEN, 4), np.int32)
+        self._check(lib.rt_sample_trace(self._h, C.byref(cam), C.byref(params), _ptr(ijk), len(ijk), _ptr(out), _ptr(trace)))
+        return out, trace
 
     def counters(self):
         c = rt_counters()

@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_spheres_kerne
 }
 
 /* one path per thread: radiance of sample (i, j, k) */
-__global__ void __launch_bounds__(RT_BLOCK) rt_sample_kernel(DScene sc, RenderArgs ra, const int32_t *ijk, int64_t n, double *out) {
+__global__ void __launch_bounds__(RT_BLOCK) rt_sample_kernel(DScene sc, RenderArgs ra, const int32_t *ijk, int64_t n, double *out, int32_t *trace) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const rt_sphere *sph;
     const RootRec *roots;
@@ -102,7 +102,10 @@ __global__ void __launch_bounds__(RT_BLOCK) rt_sample_kernel(DScene sc, RenderAr
     const bool live = q < n;
     Cnt cnt = {};
     const int i = live ? ijk[3 * q] : 0, j = live ? ijk[3 * q + 1] : 0, k = live ? ijk[3 * q + 2] : 0;
-    V3 a = trace_pixel<false, true>(sc, sc, w, sph, roots, ra, live, i, j, k, 1, cnt);
+    int32_t *tr = (trace && live) ? trace + q * 4 * RT_TRACE_LEN : nullptr;
+    if (tr)
+        for (int e = 0; e < RT_TRACE_LEN; e++) { tr[4 * e] = tr[4 * e + 1] = -1; tr[4 * e + 2] = 0; tr[4 * e + 3] = RT_TRACE_UNUSED; }
+    V3 a = trace_pixel<false, true>(sc, sc, w, sph, roots, ra, live, i, j, k, 1, cnt, tr);
     if (live) {
         out[3 * q] = a.x;
         out[3 * q + 1] = a.y;
@@ -162,7 +165,14 @@ __global__ void rt_units_add_kernel(double *accum, const double *unit_sums, int 
     accum[at] = a;
 }
 
-__global__ void rt_resolve_kernel(const double *accum, int W, int H, double spp, uint8_t *rgb) {
+/* tone[k], k = 1 .. 255: the smallest double v with pow(v, 0.45) >= k under the HOST's libm (tone_thresholds below), so
+ * the byte (unsigned char)std::min(255., pow(v, 0.45)) of raytracer.cpp:1499-1501 is the number of thresholds not above
+ * v - the same byte as the CPU program computes, whatever the device's own pow would round to at a boundary. A NaN or
+ * negative v gives pow = NaN and std::min keeps its first argument: 255. */
+__global__ void rt_resolve_kernel(const double *accum, int W, int H, double spp, const double *tone, uint8_t *rgb) {
+    __shared__ double th[256];
+    for (int k = threadIdx.x; k < 256; k += blockDim.x) th[k] = tone[k];
+    __syncthreads();
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= (int64_t)W * H) return;
     const int i = (int)(q / W), j = (int)(q - (int64_t)i * W);
@@ -170,9 +180,14 @@ __global__ void rt_resolve_kernel(const double *accum, int W, int H, double spp,
     uint8_t *o = rgb + ((int64_t)(H - i - 1) * W + j) * 3;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        double v = px[c] / spp;
-        double g = smin(255., pow(v, 0.45));
-        o[c] = (uint8_t)(int)g; /* g is in [0,255] here: a NaN power leaves 255 (std::min keeps its first argument) */
+        const double v = px[c] / spp;
+        int lo = 0, hi = 256; /* the largest k in [0, 255] with v >= th[k], th[0] = 0 */
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int mid = (lo + hi) >> 1;
+            if (v >= th[mid]) lo = mid; else hi = mid;
+        }
+        o[c] = (v != v || v < 0) ? (uint8_t)255 : (uint8_t)lo;
     }
 }
 
@@ -202,6 +217,9 @@ struct rt_ctx {
     rt_counters *d_counters = nullptr;
     int *d_overflow = nullptr;
     int *d_next_slot = nullptr;
+    double *d_tone = nullptr;    /* 256 tone-map thresholds (tone_thresholds) */
+    uint8_t *d_rgb = nullptr;    /* rt_resolve's device image, kept and grown on demand */
+    size_t d_rgb_bytes = 0;
     unsigned char *static_scratch = nullptr; /* this device's copy of `scratch` (hipGetSymbolAddress at rt_create) */
     int n_cus = 256;
     int waves_per_cu = 8;
@@ -209,6 +227,26 @@ struct rt_ctx {
 };
 
 static std::string g_create_err;
+
+/* Thresholds of the tone map for rt_resolve_kernel: T[0] = 0 and T[k] = the smallest double v >= 0 with
+ * pow(v, 0.45) >= k, found by bisection over the bit patterns (which order like the values for v >= 0) with the host's
+ * pow - the function the reference calls at raytracer.cpp:1499-1501. Relies on pow(., 0.45) not decreasing across a
+ * threshold, which tests/test_host.py checks around every one of them. */
+static void tone_thresholds(double *T) {
+    T[0] = 0.0;
+    for (int k = 1; k < 256; k++) {
+        uint64_t lo = 0, hi;
+        const double top = 1e7; /* pow(1e7, 0.45) = 1412 */
+        memcpy(&hi, &top, 8);
+        while (hi - lo > 1) {
+            const uint64_t mid = lo + (hi - lo) / 2;
+            double v;
+            memcpy(&v, &mid, 8);
+            if (pow(v, 0.45) >= (double)k) hi = mid; else lo = mid;
+        }
+        memcpy(&T[k], &hi, 8);
+    }
+}
 
 static int fail(rt_ctx *c, int code, const char *fmt, ...) {
     char buf[512];
@@ -278,7 +316,7 @@ int rt_create(int device, rt_ctx **out) {
         (e = hipMalloc((void **)&c->d_counters, RT_COUNTER_WORDS * 8)) != hipSuccess ||
         (e = hipMemset(c->d_counters, 0, RT_COUNTER_WORDS * 8)) != hipSuccess ||
         (e = hipMalloc((void **)&c->d_overflow, sizeof(int))) != hipSuccess || (e = hipMemset(c->d_overflow, 0, sizeof(int))) != hipSuccess ||
-        (e = hipMalloc((void **)&c->d_next_slot, sizeof(int))) != hipSuccess) {
+        (e = hipMalloc((void **)&c->d_next_slot, sizeof(int))) != hipSuccess || (e = hipMalloc((void **)&c->d_tone, 256 * sizeof(double))) != hipSuccess) {
         fail(nullptr, RT_E_DEVICE, "rt_create: %s", hipGetErrorString(e));
         delete c;
         return RT_E_DEVICE;
@@ -286,6 +324,15 @@ int rt_create(int device, rt_ctx **out) {
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
+    }
+    {
+        double T[256];
+        tone_thresholds(T);
+        if ((e = hipMemcpy(c->d_tone, T, sizeof T, hipMemcpyHostToDevice)) != hipSuccess) {
+            fail(nullptr, RT_E_DEVICE, "rt_create: %s", hipGetErrorString(e));
+            rt_destroy(c);
+            return RT_E_DEVICE;
+        }
     }
     /* every GPU holds its own copy of the static scratch array at its own address: ask with this device current */
     if ((e = hipGetSymbolAddress((void **)&c->static_scratch, HIP_SYMBOL(scratch))) != hipSuccess || c->static_scratch == nullptr) {
@@ -307,6 +354,8 @@ void rt_destroy(rt_ctx *c) {
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_overflow) (void)hipFree(c->d_overflow);
     if (c->d_next_slot) (void)hipFree(c->d_next_slot);
+    if (c->d_tone) (void)hipFree(c->d_tone);
+    if (c->d_rgb) (void)hipFree(c->d_rgb);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -985,15 +1034,21 @@ int rt_resolve(rt_ctx *c, const double *accum, int32_t W, int32_t H, double spp_
         accum = c->accum;
     }
     HIPCHK(c, hipSetDevice(c->device));
-    uint8_t *d = nullptr;
     const size_t nb = (size_t)W * H * 3;
-    if (hipMalloc((void **)&d, nb) != hipSuccess) return fail(c, RT_E_NOMEM, "resolve buffer allocation failed");
+    if (c->d_rgb_bytes < nb) { /* kept for the following calls */
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->d_rgb) (void)hipFree(c->d_rgb);
+        c->d_rgb = nullptr;
+        c->d_rgb_bytes = 0;
+        if (hipMalloc((void **)&c->d_rgb, nb) != hipSuccess) return fail(c, RT_E_NOMEM, "resolve buffer allocation failed");
+        c->d_rgb_bytes = nb;
+    }
+    uint8_t *d = c->d_rgb;
     const int64_t n = (int64_t)W * H;
-    hipLaunchKernelGGL(rt_resolve_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, accum, W, H, spp_total, d);
+    hipLaunchKernelGGL(rt_resolve_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, accum, W, H, spp_total, c->d_tone, d);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(rgb8_host, d, nb, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d);
     if (e != hipSuccess) return fail(c, RT_E_DEVICE, "rt_resolve: %s", hipGetErrorString(e));
     return check_overflow(c);
 }
@@ -1027,6 +1082,10 @@ int rt_intersect_rays(rt_ctx *c, const double *rays, int64_t n, int32_t *obj_id,
 }
 
 int rt_sample_radiance(rt_ctx *c, const rt_camera *cam, const rt_params *p, const int32_t *ijk, int64_t n, double *out) {
+    return rt_sample_trace(c, cam, p, ijk, n, out, nullptr);
+}
+
+int rt_sample_trace(rt_ctx *c, const rt_camera *cam, const rt_params *p, const int32_t *ijk, int64_t n, double *out, int32_t *trace) {
     if (!c) return RT_E_INVALID;
     RenderArgs ra;
     int rc = check_render_args(c, cam, p, &ra);
@@ -1038,19 +1097,21 @@ int rt_sample_radiance(rt_ctx *c, const rt_camera *cam, const rt_params *p, cons
             return fail(c, RT_E_INVALID, "sample %lld outside the image", (long long)q);
     HIPCHK(c, hipSetDevice(c->device));
     unsigned char *d = nullptr;
-    const size_t b_in = (size_t)n * 3 * 4, b_out = (size_t)n * 3 * 8;
-    if (hipMalloc((void **)&d, b_out + b_in) != hipSuccess) return fail(c, RT_E_NOMEM, "probe buffer allocation failed");
+    const size_t b_in = (size_t)n * 3 * 4, b_out = (size_t)n * 3 * 8, b_tr = trace ? (size_t)n * RT_TRACE_LEN * 4 * 4 : 0;
+    if (hipMalloc(&d, b_out + b_in + b_tr) != hipSuccess) return fail(c, RT_E_NOMEM, "probe buffer allocation failed");
     double *d_out = (double *)d;
     int32_t *d_in = (int32_t *)(d + b_out);
+    int32_t *d_tr = trace ? (int32_t *)(d + b_out + b_in) : nullptr;
     hipError_t e = hipMemcpyAsync(d_in, ijk, b_in, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(rt_sample_kernel, dim3((unsigned)((n + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, d_in, n, d_out);
+        hipLaunchKernelGGL(rt_sample_kernel, dim3((unsigned)((n + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, d_in, n, d_out, d_tr);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, b_out, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && trace) e = hipMemcpyAsync(trace, d_tr, b_tr, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
-    if (e != hipSuccess) return fail(c, RT_E_DEVICE, "rt_sample_radiance: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return fail(c, RT_E_DEVICE, "rt_sample_trace: %s", hipGetErrorString(e));
     return check_overflow(c);
 }
 
@@ -1096,6 +1157,13 @@ int rt_debug_scene_sizes(rt_ctx *c, uint64_t *out4) {
 int rt_debug_probe_prune(rt_ctx *c, int on) {
     if (!c) return RT_E_INVALID;
     c->probe_prune = on != 0;
+    return RT_OK;
+}
+
+/* not part of the public header: the 256 tone-map thresholds as the host computes them (no GPU needed; tests/ only) */
+int rt_debug_tone_table(double *out256) {
+    if (!out256) return RT_E_INVALID;
+    tone_thresholds(out256);
     return RT_OK;
 }
 

@@ -39,6 +39,7 @@
 #include <stdint.h>
 
 #include "rt_amd.h"
+#include "rt_math.h"
 
 namespace rtd {
 
@@ -1125,8 +1126,8 @@ __device__ __forceinline__ void hit_surface(const DScene &sc, SP sph, V3 C, V3 u
 
 /* random_cos, raytracer.cpp:112-138 */
 __device__ __forceinline__ V3 random_cos(double u1, double u2, V3 N) {
-    double sn, cs; /* one argument reduction for both (same values as separate calls) */
-    sincos(2 * RT_PI * u1, &sn, &cs);
+    double sn, cs; /* rt_math.h: the same bits as the CPU checker computes with the same function */
+    rtm::sincos_0_7(2 * RT_PI * u1, &sn, &cs);
     double x = cs * sqrt(1 - u2);
     double y = sn * sqrt(1 - u2);
     double z = sqrt(u2);
@@ -1189,13 +1190,15 @@ __device__ __forceinline__ void path_fresh(const RenderArgs &ra, Path &q, int i,
     } else { /* raytracer.cpp:1467-1483 */
         double u1 = rng_uniform(q.key, 0), u2 = rng_uniform(q.key, 1);
         double s1, c1, s3, c3;
-        sincos(2 * RT_PI * u1, &s1, &c1);
-        double x1 = cam.aa_sigma * c1 * sqrt(-2 * log(u2)),
-               x2 = cam.aa_sigma * s1 * sqrt(-2 * log(u2));
+        rtm::sincos_0_7(2 * RT_PI * u1, &s1, &c1);
+        const double l2 = rtm::log_pos(u2);
+        double x1 = cam.aa_sigma * c1 * sqrt(-2 * l2),
+               x2 = cam.aa_sigma * s1 * sqrt(-2 * l2);
         double u3 = rng_uniform(q.key, 2), u4 = rng_uniform(q.key, 3);
-        sincos(2 * RT_PI * u3, &s3, &c3);
-        double x3 = cam.dof_sigma * c3 * sqrt(-2 * log(u4)),
-               x4 = cam.dof_sigma * s3 * sqrt(-2 * log(u4));
+        rtm::sincos_0_7(2 * RT_PI * u3, &s3, &c3);
+        const double l4 = rtm::log_pos(u4);
+        double x3 = cam.dof_sigma * c3 * sqrt(-2 * l4),
+               x4 = cam.dof_sigma * s3 * sqrt(-2 * l4);
         q.ctr = 4;
         V3 d = mk(j - p.W / 2 + x2 + 0.5, i - p.H / 2 + x1 + 0.5, cam.zdist);
         d = unit(d);
@@ -1218,11 +1221,12 @@ __device__ __forceinline__ void path_fresh(const RenderArgs &ra, Path &q, int i,
  * terms. Leaves the next ray(s) in the state or ends the sample (fresh = true). */
 template <bool CNT, bool PLAIN = false, typename SP>
 __device__ __forceinline__ void path_advance(const DScene &sc, SP sph, const RenderArgs &ra, Path &q, bool inter,
-                                             const HitRec &h, bool inter_s, const HitRec &hs, Cnt &cnt) {
+                                             const HitRec &h, bool inter_s, const HitRec &hs, Cnt &cnt, int &branch) {
     const rt_params &p = ra.p;
     const uint32_t fl = PLAIN ? 0u : p.flags;
     const double epsilon = p.epsilon;
     bool done = false;
+    branch = RT_TRACE_NONE; /* what is done with the segment's hit (the probe's path trace; unused by the render kernels) */
     if (q.shadow) {
         /* raytracer.cpp:1073-1083 (or :1048-1055 for the point light): occluded iff hit before the light */
         if (!(inter_s && hs.t < q.sh_limit)) q.Lsum = add(q.Lsum, cmul(q.T, q.nee));
@@ -1244,6 +1248,7 @@ __device__ __forceinline__ void path_advance(const DScene &sc, SP sph, const Ren
             double e = sc.I / (4 * RT_PI * RT_PI * sqr(sc.lightR));
             q.Lsum = add(q.Lsum, cmul(q.T, mk(e, e, e)));
         }
+        branch = RT_TRACE_LIGHT;
         done = true;
     } else {
         Surf s;
@@ -1251,6 +1256,7 @@ __device__ __forceinline__ void path_advance(const DScene &sc, SP sph, const Ren
         const V3 P = s.P, N = s.N, ru = q.ru;
         if (s.flags & RT_MAT_MIRROR) { /* :974-979 */
             if (CNT) cnt.specular++;
+            branch = RT_TRACE_MIRROR;
             V3 rd = sub(ru, smul(2 * dot(ru, N), N));
             q.rC = add(P, smul(epsilon, N));
             q.ru = rd;
@@ -1277,6 +1283,7 @@ __device__ __forceinline__ void path_advance(const DScene &sc, SP sph, const Ren
                 q.ctr++;
                 reflect = (random <= 100 * R);
             }
+            branch = rad < 0 ? RT_TRACE_TOTAL_REFLECTION : (reflect ? RT_TRACE_REFLECT : RT_TRACE_REFRACT);
             if (reflect) { /* offset along N, not N2: :997, :1011 */
                 V3 rd = sub(ru, smul(2 * dot(ru, N), N));
                 q.rC = add(P, smul(epsilon, N));
@@ -1291,6 +1298,7 @@ __device__ __forceinline__ void path_advance(const DScene &sc, SP sph, const Ren
             q.lastDiffuse = false;
         } else { /* diffuse: the shadow ray and the indirect ray, traced together */
             if (CNT) cnt.diffuse++;
+            branch = RT_TRACE_DIFFUSE_LIT; /* until the shadow ray's answer says otherwise */
             const V3 Lpos = ld3(sc.L);
             V3 shC = add(P, smul(0.00001, N)), shU;
             if (fl & RT_F_POINT_LIGHT) { /* :1040-1055 */
@@ -1343,7 +1351,7 @@ __device__ __forceinline__ void path_advance(const DScene &sc, SP sph, const Ren
  * live == false only help in the pool. */
 template <bool CNT, bool SPH, typename SP>
 __device__ __forceinline__ V3 trace_pixel(const DScene &sc, const DScene &cold, WaveLDS *w, SP sph, const RootRec *roots, const RenderArgs &ra, bool live, int i,
-                                          int j, int k0, int nk, Cnt &cnt) {
+                                          int j, int k0, int nk, Cnt &cnt, int32_t *trace = nullptr) {
     Path q;
     path_begin(q, k0, live);
     const int kend = k0 + nk;
@@ -1358,7 +1366,26 @@ __device__ __forceinline__ V3 trace_pixel(const DScene &sc, const DScene &cold, 
         const RayQ qb = RayQ{!q.finished && q.shadow, q.shC, q.shU, q.sh_limit, true};
         scene_closest_wave<CNT, SPH>(sc, cold, w, sph, roots, qa, qb, !(ra.p.flags & RT_F_NO_PRUNE), h, hs, cnt);
         if (CNT) sp0 = RT_STAMP();
-        if (!q.finished) path_advance<CNT>(cold, sph, ra, q, h.obj != INT32_MAX, h, hs.obj != INT32_MAX, hs, cnt);
+        if (!q.finished) {
+            /* the probe's path trace (rt_sample_trace; nk == 1): entry d belongs to the query at recursion depth d */
+            const bool inter = h.obj != INT32_MAX, inter_s = hs.obj != INT32_MAX;
+            const int d_vertex = q.rebond, d_seg = q.rebond + ((q.shadow && q.segment) ? 1 : 0);
+            const bool had_shadow = q.shadow, had_seg = q.segment;
+            const uint32_t draws = q.ctr;
+            const bool occluded = inter_s && hs.t < q.sh_limit;
+            int branch;
+            path_advance<CNT>(cold, sph, ra, q, inter, h, inter_s, hs, cnt, branch);
+            if (trace) {
+                if (had_shadow && occluded && d_vertex < RT_TRACE_LEN) trace[4 * d_vertex + 3] = RT_TRACE_DIFFUSE_SHADOWED;
+                if (had_seg && d_seg < RT_TRACE_LEN) {
+                    int32_t *e = trace + 4 * d_seg;
+                    e[0] = inter ? h.obj : -1;
+                    e[1] = (inter && h.mesh >= 0 && h.prim >= 0) ? sc.tris[h.prim].orig_id : -1;
+                    e[2] = (int32_t)draws;
+                    e[3] = branch;
+                }
+            }
+        }
         if (CNT) cnt.cyc_shade += RT_STAMP() - sp0;
     }
     return q.acc;
@@ -1453,7 +1480,8 @@ __device__ __forceinline__ void render_persistent(const DScene &sc, const DScene
         const RayQ qb = RayQ{!q.finished && q.shadow, q.shC, q.shU, q.sh_limit, true};
         scene_closest_wave<CNT, SPH>(sc, cold, w, sph, roots, qa, qb, PLAIN ? true : !(ra.p.flags & RT_F_NO_PRUNE), h, hs, cnt);
         if (CNT) sp0 = RT_STAMP();
-        if (!q.finished) path_advance<CNT, PLAIN>(cold, sph, ra, q, h.obj != INT32_MAX, h, hs.obj != INT32_MAX, hs, cnt);
+        int branch; /* unused here */
+        if (!q.finished) path_advance<CNT, PLAIN>(cold, sph, ra, q, h.obj != INT32_MAX, h, hs.obj != INT32_MAX, hs, cnt, branch);
         if (CNT) cnt.cyc_shade += RT_STAMP() - sp0;
     }
 }

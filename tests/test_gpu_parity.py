@@ -1,8 +1,10 @@
 """GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the
 same seeded inputs. Bars: hit identity (object id, triangle id) and hit parameter t bit-exact;
 noise-free radiance within 1e-4 relative per pixel (in practice ~1e-15); per-sample stochastic
-radiance within 1e-9 relative for all but a handful of samples (libm differences in sin/cos/log can
-move a ray across a silhouette or flip a Fresnel coin)."""
+radiance within 1e-9 relative for EVERY sample, with the same path (object id, triangle id, draws used and
+branch taken at every depth). The oracle runs with the portable cos / sin / log of rt_math.h, the same
+functions the device code calls, so there is no libm difference to allow for; what those functions change
+against the host's libm is accounted for sample by sample in tests/test_portable_math.py."""
 import numpy as np
 import pytest
 
@@ -13,7 +15,7 @@ def _scene_pair(ob, scenes, builder, **kw):
     out = builder(**kw)
     s, cam, flags = out[0], out[1], out[2]
     objs = scenes.export_objects(s)
-    return s, cam, flags, ob.OracleScene(objs, s.I, s.L)
+    return s, cam, flags, ob.OracleScene(objs, s.I, s.L, math="portable")
 
 
 @pytest.fixture(params=["prune", "noprune"])
@@ -32,6 +34,17 @@ def _check_hits(g, o):
     assert np.array_equal(g["P"][hit], o["P"][hit])
     assert np.array_equal(g["N"][hit], o["N"][hit], equal_nan=True)
     assert np.array_equal(g["albedo"][hit], o["albedo"][hit])
+
+
+def _check_samples(gpu, orc, cam, p, ijk):
+    """radiance of every sample within 1e-9 of the oracle's and the very same path: no exceptions"""
+    g, tg = gpu.sample_trace(cam, p, ijk)
+    o, to = orc.sample_trace(cam, p, ijk)
+    rel = _rel_err(g, o)
+    assert (rel > 1e-9).sum() == 0, (int((rel > 1e-9).sum()), len(ijk), np.sort(rel)[-5:])
+    diff = np.nonzero((tg != to).any(axis=(1, 2)))[0]
+    assert len(diff) == 0, (len(diff), ijk[diff[0]], tg[diff[0]], to[diff[0]])
+    return rel
 
 
 def _rel_err(a, b):
@@ -79,7 +92,7 @@ def test_primary_hits_mesh_room(gpu, rta, scenes, ob, probe_mode):
 def test_random_rays_battle(gpu, rta, scenes, ob, probe_mode):
     """incoherent rays from inside the room against the 12-mesh scene (reduced triangle count)"""
     s, cam, flags, meta = scenes.battle(W=64, tri_scale=0.1, tex_size=64)
-    orc = ob.OracleScene(scenes.export_objects(s), s.I, s.L)
+    orc = ob.OracleScene(scenes.export_objects(s), s.I, s.L, math="portable")
     gpu.upload(s)
     rng = np.random.default_rng(5)
     n = 20000
@@ -151,7 +164,7 @@ def test_coarse_float_boxes(gpu, rta, scenes, ob, probe_mode):
         m.set_raw(v, n, uv, ix)
         m.buildBVH()
         s.add(m)
-        orc = ob.OracleScene(scenes.export_objects(s), s.I, s.L)
+        orc = ob.OracleScene(scenes.export_objects(s), s.I, s.L, math="portable")
         gpu.upload(s)
         rng = np.random.default_rng(11)
         nr = 4000
@@ -182,8 +195,7 @@ def test_flat_boxes_are_never_entered(gpu, rta, scenes, ob, probe_mode):
     W = 64
     p = rta.make_params(W, W, 2, flags=flags)
     ijk = np.array([(i, j, k) for i in range(0, W, 2) for j in range(0, W, 2) for k in range(2)], np.int32)
-    rel = _rel_err(gpu.sample_radiance(cam, p, ijk), orc.sample_radiance(cam, p, ijk))
-    assert (rel > 1e-9).sum() <= 2, np.sort(rel)[-5:]
+    _check_samples(gpu, orc, cam, p, ijk)
 
 
 def test_converged_image_rmse(gpu, rta, scenes, ob):
@@ -229,11 +241,7 @@ def test_stochastic_per_sample(gpu, rta, scenes, ob, name, kw):
     W = kw["W"]
     p = rta.make_params(W, W, 4, flags=flags)
     ijk = np.array([(i, j, k) for i in range(0, W, 2) for j in range(0, W, 2) for k in range(4)], np.int32)
-    g = gpu.sample_radiance(cam, p, ijk)
-    o = orc.sample_radiance(cam, p, ijk)
-    rel = _rel_err(g, o)
-    bad = (rel > 1e-9).sum()
-    assert bad <= max(2, len(ijk) // 2000), (bad, len(ijk), np.sort(rel)[-5:])
+    _check_samples(gpu, orc, cam, p, ijk)
 
 
 @pytest.mark.parametrize("kind", ["light_only", "one_triangle", "coincident_triangles", "mesh_behind_camera"])
@@ -264,7 +272,7 @@ def test_minimal_scenes(gpu, rta, scenes, ob, probe_mode, kind):
         m.buildBVH()
         s.add(m)
     cam = scenes.make_camera((0, 30, 55), 60.0, -25.0, 0.0, W)
-    orc = ob.OracleScene(scenes.export_objects(s), s.I, s.L)
+    orc = ob.OracleScene(scenes.export_objects(s), s.I, s.L, math="portable")
     gpu.upload(s)
     rays, _ = ob.primary_rays(cam, W, W)
     extra = scenes.rays_into_box(2000, 3, (-30, -10, -20), (30, 60, 60), (-25, -10, -15), (25, 55, 45))
@@ -275,8 +283,7 @@ def test_minimal_scenes(gpu, rta, scenes, ob, probe_mode, kind):
     _check_hits(g, o)
     p = rta.make_params(W, W, 2)
     ijk = np.array([(i, j, k) for i in range(0, W, 2) for j in range(0, W, 2) for k in range(2)], np.int32)
-    rel = _rel_err(gpu.sample_radiance(cam, p, ijk), orc.sample_radiance(cam, p, ijk))
-    assert (rel > 1e-9).sum() <= 2, np.sort(rel)[-5:]
+    _check_samples(gpu, orc, cam, p, ijk)
     gpu.accum_clear(W, W)
     gpu.render(cam, p)
     img = gpu.resolve(W, W, 2)
@@ -298,9 +305,7 @@ def test_many_spheres_and_one_big_mesh(gpu, rta, scenes, ob, probe_mode, n_spher
     _check_hits(g, o)
     p = rta.make_params(W, W, 2, flags=flags)
     ijk = np.array([(i, j, k) for i in range(0, W, 2) for j in range(0, W, 2) for k in range(2)], np.int32)
-    rel = _rel_err(gpu.sample_radiance(cam, p, ijk), orc.sample_radiance(cam, p, ijk))
-    bad = (rel > 1e-9).sum()
-    assert bad <= max(2, len(ijk) // 1000), (bad, len(ijk), np.sort(rel)[-5:])
+    _check_samples(gpu, orc, cam, p, ijk)
 
 
 def test_render_equals_sum_of_samples(gpu, rta, scenes, ob):
@@ -315,7 +320,7 @@ def test_render_equals_sum_of_samples(gpu, rta, scenes, ob):
     o = orc.render(cam, rta.make_params(W, W, 5, rect=(8, 16, 56, 48)))
     assert np.all(g[:16] == 0) and np.all(g[:, :8] == 0) and np.all(g[48:] == 0) and np.all(g[:, 56:] == 0)
     rel = np.abs(g - o) / np.maximum(np.abs(o), 1e-3)
-    assert (rel > 1e-9).sum() <= 6, np.sort(rel.ravel())[-8:]
+    assert (rel > 1e-9).sum() == 0, np.sort(rel.ravel())[-8:]
 
 
 def test_counters_match_oracle(gpu, rta, scenes, ob):
@@ -333,7 +338,7 @@ def test_counters_match_oracle(gpu, rta, scenes, ob):
     oc = oc.as_dict()
     assert gc["paths"] == oc["paths"] == W * W * 2
     for k in ("rays", "box_tests", "nodes", "tris", "mesh_calls", "diffuse", "specular"):
-        assert abs(gc[k] - oc[k]) <= 1e-4 * oc[k] + 50, (k, gc[k], oc[k])
+        assert gc[k] == oc[k], (k, gc[k], oc[k])  # the same paths, so the same work to the last triangle
 
 
 def test_pruning_changes_work_not_results(gpu, rta, scenes, ob):

@@ -17,8 +17,8 @@ r.render(cam, rta.make_params(W, W, spp, spp_offset=1, flags=fl)); r.sync()
 ms = r.last_render_ms()[0]
 out = dict(n_tris=info["n_tris"], n_spheres=info["n_spheres"], MB=round(info["bytes"] / 1e6, 1), build_s=round(t1 - t0, 1), upload_s=round(t2 - t1, 1),
            spp=spp, Mpaths_s=round(W * W * spp / ms / 1e3, 2))
-if n_tris <= 2_000_000:
-    orc = ob.OracleScene(scenes.export_objects(s), s.I, s.L)
+if True:
+    orc = ob.OracleScene(scenes.export_objects(s), s.I, s.L, math="portable")
     ijk = np.array([(i, j, 0) for i in range(100, W, W // 12) for j in range(50, W, W // 12)], np.int32)
     p = rta.make_params(W, W, 1, flags=fl)
     g, o = r.sample_radiance(cam, p, ijk), orc.sample_radiance(cam, p, ijk)
