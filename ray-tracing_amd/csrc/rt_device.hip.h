@@ -40,6 +40,14 @@
 
 #include "rt_amd.h"
 #include "rt_math.h"
+/* cos / sin / log of the sampling code: rt_math.h's functions as real calls. Inlined, their constants and temporaries
+ * lengthen the caller's live ranges: 256 VGPRs with spills and 7 % less throughput, against 237 VGPRs without spills. */
+namespace rtd {
+__device__ __noinline__ double2 dev_sincos(double x) { double s, c; rtm::sincos_0_7(x, &s, &c); return make_double2(s, c); }
+__device__ __noinline__ double dev_log(double x) { return rtm::log_pos(x); }
+}
+#define RT_SINCOS(arg_, ps_, pc_) do { const double2 sc_ = rtd::dev_sincos(arg_); *(ps_) = sc_.x; *(pc_) = sc_.y; } while (0)
+#define RT_LOG(arg_) rtd::dev_log(arg_)
 
 namespace rtd {
 
@@ -1127,7 +1135,7 @@ __device__ __forceinline__ void hit_surface(const DScene &sc, SP sph, V3 C, V3 u
 /* random_cos, raytracer.cpp:112-138 */
 __device__ __forceinline__ V3 random_cos(double u1, double u2, V3 N) {
     double sn, cs; /* rt_math.h: the same bits as the CPU checker computes with the same function */
-    rtm::sincos_0_7(2 * RT_PI * u1, &sn, &cs);
+    RT_SINCOS(2 * RT_PI * u1, &sn, &cs);
     double x = cs * sqrt(1 - u2);
     double y = sn * sqrt(1 - u2);
     double z = sqrt(u2);
@@ -1190,13 +1198,13 @@ __device__ __forceinline__ void path_fresh(const RenderArgs &ra, Path &q, int i,
     } else { /* raytracer.cpp:1467-1483 */
         double u1 = rng_uniform(q.key, 0), u2 = rng_uniform(q.key, 1);
         double s1, c1, s3, c3;
-        rtm::sincos_0_7(2 * RT_PI * u1, &s1, &c1);
-        const double l2 = rtm::log_pos(u2);
+        RT_SINCOS(2 * RT_PI * u1, &s1, &c1);
+        const double l2 = RT_LOG(u2);
         double x1 = cam.aa_sigma * c1 * sqrt(-2 * l2),
                x2 = cam.aa_sigma * s1 * sqrt(-2 * l2);
         double u3 = rng_uniform(q.key, 2), u4 = rng_uniform(q.key, 3);
-        rtm::sincos_0_7(2 * RT_PI * u3, &s3, &c3);
-        const double l4 = rtm::log_pos(u4);
+        RT_SINCOS(2 * RT_PI * u3, &s3, &c3);
+        const double l4 = RT_LOG(u4);
         double x3 = cam.dof_sigma * c3 * sqrt(-2 * l4),
                x4 = cam.dof_sigma * s3 * sqrt(-2 * l4);
         q.ctr = 4;
