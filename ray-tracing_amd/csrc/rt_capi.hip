@@ -8,6 +8,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -572,8 +575,22 @@ static bool build_sphere_tree(const rt_sphere *sph, int n_all, std::vector<rt_sp
     return true;
 }
 
+/* wall-clock stamps of rt_upload_scene's stages, printed to stderr when RT_UPLOAD_TIMING is set in the environment */
+struct StageClock {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    StageClock() : on(getenv("RT_UPLOAD_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char *what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "rt_upload_scene: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
     if (!c) return RT_E_INVALID;
+    StageClock clk;
     if (!s) return fail(c, RT_E_INVALID, "rt_upload_scene: scene is NULL");
     if (s->n_spheres < 0 || s->n_meshes < 0 || s->n_nodes < 0 || s->n_tris < 0 || s->n_tex < 0)
         return fail(c, RT_E_INVALID, "rt_upload_scene: negative count");
@@ -648,6 +665,7 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
         if (tx.W <= 0 || tx.H <= 0 || tx.offset < 0 || tx.offset + (int64_t)tx.W * tx.H * 3 > s->texel_bytes)
             return fail(c, RT_E_INVALID, "texture %d: outside the texel pool", k);
     }
+    clk.mark("validation");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_scene(c);
@@ -677,60 +695,96 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
     if ((rc = upload_array(c, s->meshes, (size_t)s->n_meshes, &d.meshes))) return rc;
     {
         /* device layouts (rt_device.hip.h): every BVH record as one float record plus two double halves */
+        const int host_thr = rtown::host_threads();
         std::vector<NodeHalf> halves((size_t)s->n_nodes * 2);
-        for (int64_t k = 0; k < s->n_nodes; k++) {
-            const rt_bvh_node &nd = s->nodes[k];
-            NodeHalf &l = halves[(size_t)k * 2], &r = halves[(size_t)k * 2 + 1];
-            memset(&l, 0, sizeof l);
-            memset(&r, 0, sizeof r);
-            for (int q = 0; q < 6; q++) { l.box[q] = nd.boxL[q]; r.box[q] = nd.boxR[q]; }
-            l.child = nd.L; l.count = nd.nL;
-            r.child = nd.R; r.count = nd.nR;
-        }
         std::vector<NodeRec32> rec32((size_t)s->n_nodes);
-        for (int64_t k = 0; k < s->n_nodes; k++) {
-            const rt_bvh_node &nd = s->nodes[k];
-            for (int a = 0; a < 6; a++) { rec32[(size_t)k].boxL[a] = (float)nd.boxL[a]; rec32[(size_t)k].boxR[a] = (float)nd.boxR[a]; }
-            rec32[(size_t)k].L = nd.L; rec32[(size_t)k].R = nd.R;
-            rec32[(size_t)k].nL = nd.nL; rec32[(size_t)k].nR = nd.nR;
-        }
+        rtown::parallel_parts(s->n_nodes, s->n_nodes >= (1 << 16) ? host_thr : 1, [&](int, int64_t k0, int64_t k1) {
+            for (int64_t k = k0; k < k1; k++) {
+                const rt_bvh_node &nd = s->nodes[k];
+                NodeHalf &l = halves[(size_t)k * 2], &r = halves[(size_t)k * 2 + 1];
+                memset(&l, 0, sizeof l);
+                memset(&r, 0, sizeof r);
+                for (int q = 0; q < 6; q++) { l.box[q] = nd.boxL[q]; r.box[q] = nd.boxR[q]; }
+                l.child = nd.L; l.count = nd.nL;
+                r.child = nd.R; r.count = nd.nR;
+                for (int a = 0; a < 6; a++) { rec32[(size_t)k].boxL[a] = (float)nd.boxL[a]; rec32[(size_t)k].boxR[a] = (float)nd.boxR[a]; }
+                rec32[(size_t)k].L = nd.L; rec32[(size_t)k].R = nd.R;
+                rec32[(size_t)k].nL = nd.nL; rec32[(size_t)k].nR = nd.nR;
+            }
+        });
+        clk.mark("spheres, record repack");
         /* Extension records: the reference's builder leaves ranges of up to hundreds of triangles unsplit (:283). Such a
          * leaf is given a tree of its own over contiguous sub-ranges of its triangles (their order, which carries the
          * tie rule, is untouched). These boxes are a filter only - a ray is kept out of a sub-range just when it
          * certainly misses its box - so they change which triangles are tested, never the result. */
         ext_depth = 0;
         {
-            std::vector<ExtJob> jobs;
-            std::vector<double> sweep;
+            /* every such leaf is a job of its own: the threads take leaves from a counter, build each leaf's records into
+             * an array of the leaf's own (record 0 = the leaf's root, children after their parents), and the arrays are
+             * appended in the order of the leaves, so the result does not depend on the thread count */
+            std::vector<ExtJob> roots;
             for (int64_t k = 0; k < s->n_nodes; k++) {
-                if (rec32[(size_t)k].nL > RT_EXT_LEAF) jobs.push_back(ExtJob{k, 0, rec32[(size_t)k].L, rec32[(size_t)k].nL, 1});
-                if (rec32[(size_t)k].nR > RT_EXT_LEAF) jobs.push_back(ExtJob{k, 1, rec32[(size_t)k].R, rec32[(size_t)k].nR, 1});
+                if (rec32[(size_t)k].nL > RT_EXT_LEAF) roots.push_back(ExtJob{k, 0, rec32[(size_t)k].L, rec32[(size_t)k].nL, 1});
+                if (rec32[(size_t)k].nR > RT_EXT_LEAF) roots.push_back(ExtJob{k, 1, rec32[(size_t)k].R, rec32[(size_t)k].nR, 1});
             }
             for (int mi = 0; mi < s->n_meshes; mi++)
-                if (s->meshes[mi].root_count > RT_EXT_LEAF) jobs.push_back(ExtJob{-1 - (int64_t)mi, 0, s->meshes[mi].root, s->meshes[mi].root_count, 1});
-            for (size_t q = 0; q < jobs.size(); q++) { /* breadth-first: children always get a larger index than their parent */
-                const ExtJob jb = jobs[q];
-                const int64_t id = (int64_t)rec32.size();
-                if (id >= (1LL << RT_NODE_BITS)) return fail(c, RT_E_INVALID, "rt_upload_scene: more than 2^25 BVH records with the extension records");
-                NodeRec32 r;
-                const int32_t nl = (jb.depth <= RT_EXT_SAH_DEPTH) ? ext_split(s->tris, jb.first, jb.count, sweep) : jb.count / 2;
-                const int32_t nr = jb.count - nl;
-                tri_range_box(s->tris, jb.first, nl, r.boxL);
-                tri_range_box(s->tris, jb.first + nl, nr, r.boxR);
-                r.L = jb.first; r.nL = nl;
-                r.R = jb.first + nl; r.nR = nr;
-                rec32.push_back(r);
-                if (jb.parent >= 0) { /* the parent's leaf entry becomes an inner child */
-                    NodeRec32 &pr = rec32[(size_t)jb.parent];
-                    if (jb.side == 0) { pr.L = (int32_t)id; pr.nL = 0; } else { pr.R = (int32_t)id; pr.nR = 0; }
-                } else {
-                    ext_root[(size_t)(-1 - jb.parent)] = (int32_t)id;
+                if (s->meshes[mi].root_count > RT_EXT_LEAF) roots.push_back(ExtJob{-1 - (int64_t)mi, 0, s->meshes[mi].root, s->meshes[mi].root_count, 1});
+            struct Part { std::vector<NodeRec32> recs; int depth = 0; };
+            std::vector<Part> parts(roots.size());
+            std::atomic<size_t> next(0);
+            auto work = [&] {
+                std::vector<ExtJob> jobs;
+                std::vector<double> sweep;
+                for (size_t t; (t = next.fetch_add(1)) < roots.size();) {
+                    Part &P = parts[t];
+                    jobs.clear();
+                    jobs.push_back(ExtJob{-1, 0, roots[t].first, roots[t].count, 1});
+                    for (size_t q = 0; q < jobs.size(); q++) { /* breadth-first: children always get a larger index than their parent */
+                        const ExtJob jb = jobs[q];
+                        const int64_t id = (int64_t)P.recs.size();
+                        NodeRec32 r;
+                        const int32_t nl = (jb.depth <= RT_EXT_SAH_DEPTH) ? ext_split(s->tris, jb.first, jb.count, sweep) : jb.count / 2;
+                        const int32_t nr = jb.count - nl;
+                        tri_range_box(s->tris, jb.first, nl, r.boxL);
+                        tri_range_box(s->tris, jb.first + nl, nr, r.boxR);
+                        r.L = jb.first; r.nL = nl;
+                        r.R = jb.first + nl; r.nR = nr;
+                        P.recs.push_back(r);
+                        if (jb.parent >= 0) { /* the parent's leaf entry becomes an inner child (index within this leaf's array for now) */
+                            NodeRec32 &pr = P.recs[(size_t)jb.parent];
+                            if (jb.side == 0) { pr.L = (int32_t)id; pr.nL = 0; } else { pr.R = (int32_t)id; pr.nR = 0; }
+                        }
+                        if (jb.depth > P.depth) P.depth = jb.depth;
+                        if (nl > RT_EXT_LEAF) jobs.push_back(ExtJob{id, 0, jb.first, nl, jb.depth + 1});
+                        if (nr > RT_EXT_LEAF) jobs.push_back(ExtJob{id, 1, jb.first + nl, nr, jb.depth + 1});
+                    }
                 }
-                if (jb.depth > ext_depth) ext_depth = jb.depth;
-                if (nl > RT_EXT_LEAF) jobs.push_back(ExtJob{id, 0, jb.first, nl, jb.depth + 1});
-                if (nr > RT_EXT_LEAF) jobs.push_back(ExtJob{id, 1, jb.first + nl, nr, jb.depth + 1});
+            };
+            {
+                const int threads = roots.size() >= 64 ? rtown::host_threads() : 1;
+                std::vector<std::thread> th;
+                for (int p = 1; p < threads; p++) th.emplace_back(work);
+                work();
+                for (auto &t : th) t.join();
+            }
+            for (size_t t = 0; t < roots.size(); t++) {
+                const int64_t off = (int64_t)rec32.size();
+                if (off + (int64_t)parts[t].recs.size() >= (1LL << RT_NODE_BITS)) return fail(c, RT_E_INVALID, "rt_upload_scene: more than 2^25 BVH records with the extension records");
+                for (NodeRec32 r : parts[t].recs) {
+                    if (r.nL == 0) r.L += (int32_t)off;
+                    if (r.nR == 0) r.R += (int32_t)off;
+                    rec32.push_back(r);
+                }
+                if (roots[t].parent >= 0) {
+                    NodeRec32 &pr = rec32[(size_t)roots[t].parent];
+                    if (roots[t].side == 0) { pr.L = (int32_t)off; pr.nL = 0; } else { pr.R = (int32_t)off; pr.nR = 0; }
+                } else {
+                    ext_root[(size_t)(-1 - roots[t].parent)] = (int32_t)off;
+                }
+                if (parts[t].depth > ext_depth) ext_depth = parts[t].depth;
             }
         }
+        clk.mark("extension records");
         /* The filter tree over the triangles of all meshes, and what confirms its winners: the reference leaf of every
          * triangle. A leaf whose box has no thickness along an axis is never entered by the reference (tMax > tMin cannot
          * hold, raytracer.cpp:184), so its triangles are left out of the filter tree: they cannot be part of any answer. */
@@ -752,17 +806,28 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
                 if (s->meshes[mi].root_count > 0) add_leaf(s->meshes[mi].root_box, s->meshes[mi].root, s->meshes[mi].root_count);
             /* a triangle outside every leaf is never reached by the reference either */
             std::vector<rt_tri> sub;
-            sub.reserve((size_t)s->n_tris);
-            for (int64_t k = 0; k < s->n_tris; k++)
-                if (tri_leaf[(size_t)k] >= 0 && !leaf_flat[(size_t)tri_leaf[(size_t)k]]) {
-                    sub.push_back(s->tris[k]);
-                    sub.back().orig_id = (int32_t)k; /* position in the reference's order */
-                }
+            {
+                std::vector<int32_t> keep;
+                keep.reserve((size_t)s->n_tris);
+                for (int64_t k = 0; k < s->n_tris; k++)
+                    if (tri_leaf[(size_t)k] >= 0 && !leaf_flat[(size_t)tri_leaf[(size_t)k]]) keep.push_back((int32_t)k);
+                sub.resize(keep.size());
+                rtown::parallel_parts((int64_t)keep.size(), keep.size() >= (1u << 16) ? host_thr : 1, [&](int, int64_t q0, int64_t q1) {
+                    for (int64_t q = q0; q < q1; q++) {
+                        sub[(size_t)q] = s->tris[keep[(size_t)q]];
+                        sub[(size_t)q].orig_id = keep[(size_t)q]; /* position in the reference's order */
+                    }
+                });
+            }
+            clk.mark("leaf table, triangle subset");
             if (!sub.empty()) {
                 rtown::Built own = rtown::build(sub.data(), (int64_t)sub.size());
+                clk.mark("filter tree build");
                 if (own.ok && (int64_t)own.nodes.size() < (1LL << RT_NODE_BITS)) {
                     std::vector<rt_tri> otris(sub.size());
-                    for (size_t k = 0; k < sub.size(); k++) otris[k] = sub[(size_t)own.order[k]];
+                    rtown::parallel_parts((int64_t)sub.size(), sub.size() >= (1u << 16) ? host_thr : 1, [&](int, int64_t k0, int64_t k1) {
+                        for (int64_t k = k0; k < k1; k++) otris[(size_t)k] = sub[(size_t)own.order[(size_t)k]];
+                    });
                     if ((rc = upload_array(c, own.wide.data(), own.wide.size(), &d.own_rec4))) return rc;
                     if ((rc = upload_array(c, otris.data(), otris.size(), &d.own_tris))) return rc;
                     if ((rc = upload_array(c, tri_leaf.data(), tri_leaf.size(), &d.tri_leaf))) return rc;
@@ -774,6 +839,7 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
                 }
             }
         }
+        clk.mark("filter tree reorder + copies");
         if ((rc = upload_array(c, rec32.data(), rec32.size(), &d.rec32))) return rc;
         d.n_nodes_total = (uint32_t)rec32.size();
         if ((rc = upload_array(c, halves.data(), halves.size(), &d.halves))) return rc;
@@ -834,6 +900,7 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
         c->waves_per_cu = per_cu < by_regs ? per_cu : by_regs;
     }
     c->have_scene = true;
+    clk.mark("remaining copies, occupancy");
     return RT_OK;
 }
 

@@ -12,7 +12,11 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "rt_amd.h"
@@ -65,26 +69,30 @@ static const int kBins = RT_OWN_BINS;
 static const int kLeaf = RT_OWN_LEAF; /* at most 8: the leaf count has three bits in a child code */
 static const int kSahDepth = 40; /* below this depth ranges are halved by count, which bounds the depth */
 
-inline Built build(const rt_tri *tris, int64_t n) {
-    Built out;
-    if (n <= 0) return out;
-    std::vector<Bounds> tb((size_t)n);
-    std::vector<double> cen((size_t)n * 3);
-    for (int64_t k = 0; k < n; k++) {
-        Bounds &b = tb[(size_t)k];
-        b.reset();
-        for (int a = 0; a < 3; a++) {
-            const double v[3] = {tris[k].A[a], tris[k].A[a] + tris[k].e1[a], tris[k].A[a] + tris[k].e2[a]};
-            for (int q = 0; q < 3; q++) {
-                if (!std::isfinite(v[q])) return out;
-                if (v[q] < b.lo[a]) b.lo[a] = v[q];
-                if (v[q] > b.hi[a]) b.hi[a] = v[q];
-            }
-            cen[(size_t)k * 3 + a] = 0.5 * (b.lo[a] + b.hi[a]);
-        }
-    }
-    std::vector<int32_t> idx((size_t)n);
-    for (int64_t k = 0; k < n; k++) idx[(size_t)k] = (int32_t)k;
+/* worker threads for the host-side builds: OMP_NUM_THREADS when it is set (job schedulers size it to the process's share
+ * of the machine), else the hardware's count, at most 64 */
+inline int host_threads() {
+    int t = 0;
+    if (const char *e = getenv("OMP_NUM_THREADS")) t = atoi(e);
+    if (t <= 0) t = (int)std::thread::hardware_concurrency();
+    if (t <= 0) t = 1;
+    return t > 64 ? 64 : t;
+}
+
+/* fn(part, begin, end) on `parts` contiguous pieces of [0, n), one thread each (the caller's thread takes piece 0) */
+template <typename F>
+inline void parallel_parts(int64_t n, int parts, F fn) {
+    if (parts <= 1 || n < 2) { fn(0, (int64_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (int p = 1; p < parts; p++) th.emplace_back([=] { fn(p, n * p / parts, n * (p + 1) / parts); });
+    fn(0, (int64_t)0, n / parts);
+    for (auto &t : th) t.join();
+}
+
+struct Builder {
+    const std::vector<Bounds> &tb;
+    const std::vector<double> &cen;
+    std::vector<int32_t> &idx;
 
     struct Job {
         int64_t node; /* record that holds this range as child `side`, or -1 for the root range */
@@ -92,20 +100,173 @@ inline Built build(const rt_tri *tris, int64_t n) {
         int64_t first, count;
         int depth;
     };
-    auto range_bounds = [&](int64_t first, int64_t count) {
+
+    Bounds range_bounds(int64_t first, int64_t count) const {
         Bounds b;
         b.reset();
         for (int64_t k = first; k < first + count; k++) b.grow(tb[(size_t)idx[(size_t)k]]);
         return b;
-    };
-    std::vector<Job> jobs;
-    jobs.push_back(Job{-1, 0, 0, n, 1});
+    }
+
+    /* Cuts [first, first + count) in two: the binned surface-area cut (kBins bins per axis over the centroids' extent),
+     * or - all centroids equal, or too deep - the median along the longest centroid axis. Reorders idx, returns the size
+     * of the left part and both parts' bounds. threads > 1: the passes over the range are shared out (the top of the
+     * tree, where one range is most of the scene). The result does not depend on the thread count. */
+    int64_t cut(int64_t first, int64_t count, int depth, int threads, Bounds &bl, Bounds &br) {
+        if (count < (1 << 16)) threads = 1;
+        int64_t nl = count / 2;
+        bool sorted = false;
+        Bounds cb;
+        cb.reset();
+        {
+            std::vector<Bounds> part((size_t)threads);
+            parallel_parts(count, threads, [&](int p, int64_t b, int64_t e) {
+                Bounds x;
+                x.reset();
+                for (int64_t k = first + b; k < first + e; k++)
+                    for (int a = 0; a < 3; a++) {
+                        const double c = cen[(size_t)idx[(size_t)k] * 3 + a];
+                        if (c < x.lo[a]) x.lo[a] = c;
+                        if (c > x.hi[a]) x.hi[a] = c;
+                    }
+                part[(size_t)p] = x;
+            });
+            for (int p = 0; p < threads; p++) cb.grow(part[(size_t)p]);
+        }
+        if (depth <= kSahDepth) {
+            struct Bins { Bounds bb[3][kBins]; int64_t bc[3][kBins]; };
+            std::vector<Bins> part((size_t)threads);
+            double scale[3];
+            for (int a = 0; a < 3; a++) scale[a] = (cb.hi[a] - cb.lo[a] > 0) ? kBins / (cb.hi[a] - cb.lo[a]) : 0;
+            parallel_parts(count, threads, [&](int p, int64_t b, int64_t e) {
+                Bins &B = part[(size_t)p];
+                for (int a = 0; a < 3; a++)
+                    for (int q = 0; q < kBins; q++) { B.bb[a][q].reset(); B.bc[a][q] = 0; }
+                for (int64_t k = first + b; k < first + e; k++) {
+                    const int32_t t = idx[(size_t)k];
+                    for (int a = 0; a < 3; a++) {
+                        if (!(scale[a] > 0)) continue;
+                        int q = (int)((cen[(size_t)t * 3 + a] - cb.lo[a]) * scale[a]);
+                        if (q >= kBins) q = kBins - 1;
+                        if (q < 0) q = 0;
+                        B.bb[a][q].grow(tb[(size_t)t]);
+                        B.bc[a][q]++;
+                    }
+                }
+            });
+            Bins &S = part[0];
+            for (int p = 1; p < threads; p++)
+                for (int a = 0; a < 3; a++)
+                    for (int q = 0; q < kBins; q++) { S.bb[a][q].grow(part[(size_t)p].bb[a][q]); S.bc[a][q] += part[(size_t)p].bc[a][q]; }
+            double best = HUGE_VAL;
+            int best_axis = -1, best_bin = 0;
+            for (int a = 0; a < 3; a++) {
+                if (!(scale[a] > 0)) continue;
+                double ra[kBins];
+                Bounds acc;
+                acc.reset();
+                int64_t cnt = 0;
+                for (int q = kBins - 1; q >= 1; q--) { acc.grow(S.bb[a][q]); cnt += S.bc[a][q]; ra[q] = cnt ? acc.half_area() * (double)cnt : 0; }
+                acc.reset();
+                cnt = 0;
+                for (int q = 0; q < kBins - 1; q++) {
+                    acc.grow(S.bb[a][q]);
+                    cnt += S.bc[a][q];
+                    if (cnt == 0 || cnt == count) continue;
+                    const double cost = acc.half_area() * (double)cnt + ra[q + 1];
+                    if (cost < best) { best = cost; best_axis = a; best_bin = q; }
+                }
+            }
+            if (best_axis >= 0) {
+                const double sc = scale[best_axis], lo = cb.lo[best_axis];
+                int32_t *beg = idx.data() + first, *end = beg + count;
+                int32_t *mid = std::partition(beg, end, [&](int32_t t) {
+                    int q = (int)((cen[(size_t)t * 3 + best_axis] - lo) * sc);
+                    if (q >= kBins) q = kBins - 1;
+                    if (q < 0) q = 0;
+                    return q <= best_bin;
+                });
+                nl = mid - beg;
+                sorted = nl > 0 && nl < count;
+                if (sorted) { /* the parts' bounds are the unions of their bins */
+                    bl.reset();
+                    br.reset();
+                    for (int q = 0; q < kBins; q++) (q <= best_bin ? bl : br).grow(S.bb[best_axis][q]);
+                    return nl;
+                }
+            }
+        }
+        /* all centroids coincide, or too deep: halve the range along its longest centroid axis */
+        nl = count / 2;
+        int axis = 0;
+        for (int a = 1; a < 3; a++)
+            if (cb.hi[a] - cb.lo[a] > cb.hi[axis] - cb.lo[axis]) axis = a;
+        std::nth_element(idx.begin() + first, idx.begin() + first + nl, idx.begin() + first + count,
+                         [&](int32_t x, int32_t y) { return cen[(size_t)x * 3 + axis] < cen[(size_t)y * 3 + axis]; });
+        bl = range_bounds(first, nl);
+        br = range_bounds(first + nl, count - nl);
+        return nl;
+    }
+
+    /* Breadth-first build of the ranges in `jobs` into `nodes` (a child's index is larger than its parent's). Ranges of at
+     * most `defer` triangles are not cut here but handed back in `deferred` (0: none are). */
+    void run(std::vector<Job> &jobs, std::vector<rtd::NodeRec32> &nodes, int &max_depth, int threads, int64_t defer, std::vector<Job> *deferred) {
+        for (size_t q = 0; q < jobs.size(); q++) {
+            const Job jb = jobs[q];
+            if (deferred && jb.count <= defer) { deferred->push_back(jb); continue; }
+            Bounds bl, br;
+            const int64_t nl = cut(jb.first, jb.count, jb.depth, threads, bl, br), nr = jb.count - nl;
+            const int64_t id = (int64_t)nodes.size();
+            rtd::NodeRec32 r;
+            box_to_float(bl, r.boxL);
+            box_to_float(br, r.boxR);
+            r.L = (int32_t)jb.first; r.nL = (int32_t)nl;
+            r.R = (int32_t)(jb.first + nl); r.nR = (int32_t)nr;
+            nodes.push_back(r);
+            if (jb.node >= 0) {
+                rtd::NodeRec32 &pr = nodes[(size_t)jb.node];
+                if (jb.side == 0) { pr.L = (int32_t)id; pr.nL = 0; } else { pr.R = (int32_t)id; pr.nR = 0; }
+            }
+            if (jb.depth > max_depth) max_depth = jb.depth;
+            if (nl > kLeaf) jobs.push_back(Job{id, 0, jb.first, nl, jb.depth + 1});
+            if (nr > kLeaf) jobs.push_back(Job{id, 1, jb.first + nl, nr, jb.depth + 1});
+        }
+    }
+};
+
+inline Built build(const rt_tri *tris, int64_t n) {
+    Built out;
+    if (n <= 0) return out;
+    const int threads = host_threads();
+    std::vector<Bounds> tb((size_t)n);
+    std::vector<double> cen((size_t)n * 3);
+    std::vector<int32_t> idx((size_t)n);
+    std::vector<char> bad((size_t)threads, 0);
+    parallel_parts(n, n >= (1 << 16) ? threads : 1, [&](int p, int64_t b0, int64_t e0) {
+        for (int64_t k = b0; k < e0; k++) {
+            Bounds &b = tb[(size_t)k];
+            b.reset();
+            for (int a = 0; a < 3; a++) {
+                const double v[3] = {tris[k].A[a], tris[k].A[a] + tris[k].e1[a], tris[k].A[a] + tris[k].e2[a]};
+                for (int q = 0; q < 3; q++) {
+                    if (!std::isfinite(v[q])) bad[(size_t)p] = 1;
+                    if (v[q] < b.lo[a]) b.lo[a] = v[q];
+                    if (v[q] > b.hi[a]) b.hi[a] = v[q];
+                }
+                cen[(size_t)k * 3 + a] = 0.5 * (b.lo[a] + b.hi[a]);
+            }
+            idx[(size_t)k] = (int32_t)k;
+        }
+    });
+    for (char x : bad)
+        if (x) return out;
+    Builder B{tb, cen, idx};
     if (n <= kLeaf) { /* a tree needs one record: both children are leaves (the right one may be empty) */
         rtd::NodeRec32 r;
         const int64_t nl = (n + 1) / 2;
-        box_to_float(range_bounds(0, nl), r.boxL);
+        box_to_float(B.range_bounds(0, nl), r.boxL);
         r.L = 0; r.nL = (int32_t)nl;
-        if (n - nl > 0) { box_to_float(range_bounds(nl, n - nl), r.boxR); r.R = (int32_t)nl; r.nR = (int32_t)(n - nl); }
+        if (n - nl > 0) { box_to_float(B.range_bounds(nl, n - nl), r.boxR); r.R = (int32_t)nl; r.nR = (int32_t)(n - nl); }
         else { for (int a = 0; a < 3; a++) { r.boxR[a] = HUGE_VALF; r.boxR[3 + a] = -HUGE_VALF; } r.R = 0; r.nR = 1; } /* inverted box: certainly missed */
         out.nodes.push_back(r);
         out.order = idx;
@@ -114,98 +275,39 @@ inline Built build(const rt_tri *tris, int64_t n) {
         collapse(out);
         return out;
     }
-    for (size_t q = 0; q < jobs.size(); q++) { /* breadth-first: a child's index is larger than its parent's */
-        const Job jb = jobs[q];
-        /* choose the cut of [first, first + count) */
-        int64_t nl = jb.count / 2;
-        bool sorted = false;
-        if (jb.depth <= kSahDepth) {
-            Bounds cb;
-            cb.reset();
-            for (int64_t k = jb.first; k < jb.first + jb.count; k++)
-                for (int a = 0; a < 3; a++) {
-                    const double c = cen[(size_t)idx[(size_t)k] * 3 + a];
-                    if (c < cb.lo[a]) cb.lo[a] = c;
-                    if (c > cb.hi[a]) cb.hi[a] = c;
-                }
-            double best = HUGE_VAL;
-            int best_axis = -1, best_bin = 0;
-            for (int a = 0; a < 3; a++) {
-                const double ext = cb.hi[a] - cb.lo[a];
-                if (!(ext > 0)) continue;
-                Bounds bb[kBins];
-                int64_t bc[kBins];
-                for (int b = 0; b < kBins; b++) { bb[b].reset(); bc[b] = 0; }
-                const double scale = kBins / ext;
-                for (int64_t k = jb.first; k < jb.first + jb.count; k++) {
-                    const int32_t t = idx[(size_t)k];
-                    int b = (int)((cen[(size_t)t * 3 + a] - cb.lo[a]) * scale);
-                    if (b >= kBins) b = kBins - 1;
-                    if (b < 0) b = 0;
-                    bb[b].grow(tb[(size_t)t]);
-                    bc[b]++;
-                }
-                double ra[kBins];
-                Bounds acc;
-                acc.reset();
-                int64_t cnt = 0;
-                for (int b = kBins - 1; b >= 1; b--) { acc.grow(bb[b]); cnt += bc[b]; ra[b] = cnt ? acc.half_area() * (double)cnt : 0; }
-                acc.reset();
-                cnt = 0;
-                for (int b = 0; b < kBins - 1; b++) {
-                    acc.grow(bb[b]);
-                    cnt += bc[b];
-                    if (cnt == 0 || cnt == jb.count) continue;
-                    const double cost = acc.half_area() * (double)cnt + ra[b + 1];
-                    if (cost < best) { best = cost; best_axis = a; best_bin = b; }
-                }
+    /* The top of the tree with all threads inside each cut; ranges below n / (8 threads) triangles are whole subtrees that
+     * the threads then build one each, into arrays of their own, appended in the order of the ranges (so the tree is
+     * the same whatever the thread count and timing). */
+    std::vector<Builder::Job> jobs, sub;
+    jobs.push_back(Builder::Job{-1, 0, 0, n, 1});
+    const int64_t defer = (threads > 1 && n >= (1 << 16)) ? n / (8 * (int64_t)threads) : 0;
+    B.run(jobs, out.nodes, out.depth, threads, defer, defer > 0 ? &sub : nullptr);
+    if (!sub.empty()) {
+        struct Part { std::vector<rtd::NodeRec32> nodes; int depth = 0; };
+        std::vector<Part> parts(sub.size());
+        std::atomic<size_t> next(0);
+        auto work = [&] {
+            for (size_t t; (t = next.fetch_add(1)) < sub.size();) {
+                std::vector<Builder::Job> local;
+                local.push_back(Builder::Job{-1, 0, sub[t].first, sub[t].count, sub[t].depth});
+                B.run(local, parts[t].nodes, parts[t].depth, 1, 0, nullptr);
             }
-            if (best_axis >= 0) {
-                const double ext = cb.hi[best_axis] - cb.lo[best_axis], scale = kBins / ext, lo = cb.lo[best_axis];
-                int32_t *beg = idx.data() + jb.first, *end = beg + jb.count;
-                int32_t *mid = std::partition(beg, end, [&](int32_t t) {
-                    int b = (int)((cen[(size_t)t * 3 + best_axis] - lo) * scale);
-                    if (b >= kBins) b = kBins - 1;
-                    if (b < 0) b = 0;
-                    return b <= best_bin;
-                });
-                nl = mid - beg;
-                sorted = nl > 0 && nl < jb.count;
+        };
+        std::vector<std::thread> th;
+        for (int p = 1; p < threads; p++) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+        for (size_t t = 0; t < sub.size(); t++) {
+            const int64_t off = (int64_t)out.nodes.size();
+            for (rtd::NodeRec32 r : parts[t].nodes) {
+                if (r.nL == 0) r.L += (int32_t)off;
+                if (r.nR == 0) r.R += (int32_t)off;
+                out.nodes.push_back(r);
             }
+            rtd::NodeRec32 &pr = out.nodes[(size_t)sub[t].node]; /* a deferred range is never the root: n > defer */
+            if (sub[t].side == 0) { pr.L = (int32_t)off; pr.nL = 0; } else { pr.R = (int32_t)off; pr.nR = 0; }
+            if (parts[t].depth > out.depth) out.depth = parts[t].depth;
         }
-        if (!sorted) { /* all centroids coincide, or too deep: halve the range along its longest centroid axis */
-            nl = jb.count / 2;
-            int axis = 0;
-            {
-                Bounds cb;
-                cb.reset();
-                for (int64_t k = jb.first; k < jb.first + jb.count; k++)
-                    for (int a = 0; a < 3; a++) {
-                        const double c = cen[(size_t)idx[(size_t)k] * 3 + a];
-                        if (c < cb.lo[a]) cb.lo[a] = c;
-                        if (c > cb.hi[a]) cb.hi[a] = c;
-                    }
-                for (int a = 1; a < 3; a++)
-                    if (cb.hi[a] - cb.lo[a] > cb.hi[axis] - cb.lo[axis]) axis = a;
-            }
-            std::nth_element(idx.begin() + jb.first, idx.begin() + jb.first + nl, idx.begin() + jb.first + jb.count,
-                             [&](int32_t x, int32_t y) { return cen[(size_t)x * 3 + axis] < cen[(size_t)y * 3 + axis]; });
-        }
-        const int64_t nr = jb.count - nl;
-        const int64_t id = (int64_t)out.nodes.size();
-        rtd::NodeRec32 r;
-        box_to_float(range_bounds(jb.first, nl), r.boxL);
-        box_to_float(range_bounds(jb.first + nl, nr), r.boxR);
-        r.L = (int32_t)jb.first; r.nL = (int32_t)nl;
-        r.R = (int32_t)(jb.first + nl); r.nR = (int32_t)nr;
-        out.nodes.push_back(r);
-        if (jb.node >= 0) {
-            rtd::NodeRec32 &pr = out.nodes[(size_t)jb.node];
-            if (jb.side == 0) { pr.L = (int32_t)id; pr.nL = 0; } else { pr.R = (int32_t)id; pr.nR = 0; }
-        }
-        if (jb.depth > out.depth) out.depth = jb.depth;
-        if (nl > kLeaf) jobs.push_back(Job{id, 0, jb.first, nl, jb.depth + 1});
-        if (nr > kLeaf) jobs.push_back(Job{id, 1, jb.first + nl, nr, jb.depth + 1});
     }
     out.order = idx;
     out.ok = true;

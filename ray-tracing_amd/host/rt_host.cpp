@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <memory>
+#include <thread>
 
 namespace rt {
 
@@ -364,8 +365,28 @@ size_t FlatScene::bytes() const {
            tris.size() * (sizeof(rt_tri) + sizeof(rt_tri_attr)) + tex.size() * sizeof(rt_texture) + texels.size() + sizeof lut;
 }
 
+namespace {
+int flatten_threads() { /* OMP_NUM_THREADS when set (a scheduler's share of the machine), else the hardware's count, at most 64 */
+    int t = 0;
+    if (const char *e = getenv("OMP_NUM_THREADS")) t = atoi(e);
+    if (t <= 0) t = (int)std::thread::hardware_concurrency();
+    return t <= 0 ? 1 : (t > 64 ? 64 : t);
+}
+} // namespace
+
 void flatten(const Scene &scene, FlatScene &out) {
     out = FlatScene();
+    {
+        size_t nt = 0, ntexel = 0;
+        for (const Object *o : scene.objects)
+            if (const TriangleMesh *m = dynamic_cast<const TriangleMesh *>(o)) {
+                nt += m->indices.size();
+                for (const auto &t : m->textures) ntexel += t.size();
+            }
+        out.tris.reserve(nt);
+        out.attrs.reserve(nt);
+        out.texels.reserve(ntexel);
+    }
     out.I = scene.I;
     for (int k = 0; k < 3; k++) out.L[k] = scene.L[k];
     for (int i = 0; i < 256; i++) out.lut[i] = pow(i / 255., 2.2); /* :713-715 */
@@ -419,34 +440,51 @@ void flatten(const Scene &scene, FlatScene &out) {
         /* A, e1 = B - A, e2 = C - A (:673-677) and the gathered attributes */
         const int nn = (int)m->normals.size(), nuv = (int)m->uvs.size();
         const int32_t mesh_index = (int32_t)out.meshes.size();
-        for (size_t vk = 0; vk < visit.size(); vk++) {
-            const size_t k = (size_t)visit[vk];
-            const TriangleIndices &t = m->indices[k];
-            const Vector &A = m->vertices[t.vtxi], &B = m->vertices[t.vtxj], &C = m->vertices[t.vtxk];
-            Vector e1 = B - A, e2 = C - A;
-            rt_tri rt_;
-            for (int q = 0; q < 3; q++) { rt_.A[q] = A[q]; rt_.e1[q] = e1[q]; rt_.e2[q] = e2[q]; }
-            rt_.orig_id = m->order[k];
-            rt_.mesh = mesh_index;
-            out.tris.push_back(rt_);
-            rt_tri_attr at;
-            memset(&at, 0, sizeof at);
-            const int ni[3] = {t.ni, t.nj, t.nk}, ui[3] = {t.uvi, t.uvj, t.uvk};
-            for (int q = 0; q < 3; q++) {
-                /* the reference reads normals[ni] unchecked (:694); a missing normal is an error here */
-                if (ni[q] < 0 || ni[q] >= nn) throw std::runtime_error("flatten: a triangle has no vertex normal (the reference interpolates normals[ni], raytracer.cpp:694)");
-                for (int d = 0; d < 3; d++) at.n[q][d] = m->normals[ni[q]][d];
-                if (rm.n_tex > 0) {
-                    if (ui[q] < 0 || ui[q] >= nuv) throw std::runtime_error("flatten: a textured triangle has no uv (raytracer.cpp:702)");
-                    at.uv[q][0] = m->uvs[ui[q]][0];
-                    at.uv[q][1] = m->uvs[ui[q]][1];
+        const size_t base = out.tris.size();
+        out.tris.resize(base + visit.size());
+        out.attrs.resize(base + visit.size());
+        /* the triangles are independent: large meshes are filled by several threads; the first error of each is kept */
+        const int threads = visit.size() >= (1u << 16) ? flatten_threads() : 1;
+        std::vector<const char *> err((size_t)threads, nullptr);
+        auto fill = [&](int part, size_t vk0, size_t vk1) {
+            for (size_t vk = vk0; vk < vk1; vk++) {
+                const size_t k = (size_t)visit[vk];
+                const TriangleIndices &t = m->indices[k];
+                const Vector &A = m->vertices[t.vtxi], &B = m->vertices[t.vtxj], &C = m->vertices[t.vtxk];
+                Vector e1 = B - A, e2 = C - A;
+                rt_tri &rt_ = out.tris[base + vk];
+                for (int q = 0; q < 3; q++) { rt_.A[q] = A[q]; rt_.e1[q] = e1[q]; rt_.e2[q] = e2[q]; }
+                rt_.orig_id = m->order[k];
+                rt_.mesh = mesh_index;
+                rt_tri_attr &at = out.attrs[base + vk];
+                memset(&at, 0, sizeof at);
+                const int ni[3] = {t.ni, t.nj, t.nk}, ui[3] = {t.uvi, t.uvj, t.uvk};
+                for (int q = 0; q < 3; q++) {
+                    /* the reference reads normals[ni] unchecked (:694); a missing normal is an error here */
+                    if (ni[q] < 0 || ni[q] >= nn) { err[(size_t)part] = "flatten: a triangle has no vertex normal (the reference interpolates normals[ni], raytracer.cpp:694)"; return; }
+                    for (int d = 0; d < 3; d++) at.n[q][d] = m->normals[ni[q]][d];
+                    if (rm.n_tex > 0) {
+                        if (ui[q] < 0 || ui[q] >= nuv) { err[(size_t)part] = "flatten: a textured triangle has no uv (raytracer.cpp:702)"; return; }
+                        at.uv[q][0] = m->uvs[ui[q]][0];
+                        at.uv[q][1] = m->uvs[ui[q]][1];
+                    }
+                }
+                at.group = t.group;
+                if (rm.n_tex > 0 && (t.group < 0 || t.group >= rm.n_tex)) {
+                    err[(size_t)part] = "flatten: triangle texture group outside the mesh's textures (raytracer.cpp:700-701 would read out of bounds)";
+                    return;
                 }
             }
-            at.group = t.group;
-            if (rm.n_tex > 0 && (t.group < 0 || t.group >= rm.n_tex))
-                throw std::runtime_error("flatten: triangle texture group outside the mesh's textures (raytracer.cpp:700-701 would read out of bounds)");
-            out.attrs.push_back(at);
+        };
+        {
+            std::vector<std::thread> th;
+            const size_t n = visit.size();
+            for (int p = 1; p < threads; p++) th.emplace_back(fill, p, n * (size_t)p / (size_t)threads, n * (size_t)(p + 1) / (size_t)threads);
+            fill(0, 0, n / (size_t)threads);
+            for (auto &t : th) t.join();
         }
+        for (const char *e : err)
+            if (e) throw std::runtime_error(e);
         /* nodes: one record per inner Noeud holding both child boxes; children get larger indices */
         if (m->bvh[0].fg < 0) {
             rm.root = leaf_new_first[(size_t)m->bvh[0].debut];
