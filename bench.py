@@ -1,21 +1,29 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Mpaths/s on the final battle scene (raytracer.cpp:1222-1435), 1024x1024.
+"""Benchmark of the path-tracing hot path: Mpaths/s and time-to-image.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config cfg1|cfg2|cfg3|cfg4|cfg5]
   (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A step = every rank renders --spp-step samples of every pixel of the 1024x1024 frame (1 path =
-1 camera sample = one Scene::getColor(r,0,false) call, raytracer.cpp:1485). Ranks own disjoint global
-sample indices (spp sharding; weak scaling: per-rank work per step is fixed). Inside the timed
-region, after the K steps, the FP64 radiance accumulators are summed onto rank 0 (RCCL reduce over
-xGMI) and rank 0 resolves the 8-bit image, so `value` includes everything between "scene resident
-in HBM" and "image in host memory". Scene upload and BVH build are outside the timed region.
+Default workload = cfg4, the configuration the metric is quoted on: the final battle scene of main()
+(raytracer.cpp:1222-1435) at 1024 x 1024. The other configurations of BASELINE.json can be selected for
+profiling; they share every line of this script.
 
-The OBJ/JPG assets of the reference are not redistributable and are absent on the GPU box:
-procedural stand-ins of the same triangle counts, object-space extents and transform chains are
-used (ray-tracing_amd/scenes.py: battle()).
+A step = every rank renders --spp-step samples of every pixel of the frame (1 path = 1 camera sample = one
+Scene::getColor(r,0,false) call, raytracer.cpp:1485). Ranks own disjoint global sample indices (spp sharding;
+weak scaling: per-rank work per step is fixed). Inside the timed region, after the K steps, the FP64 radiance
+accumulators are summed onto rank 0 (RCCL reduce over xGMI) and rank 0 resolves the 8-bit image, so `value`
+covers everything between "scene resident in HBM" and "image in host memory". Nothing waits between the steps:
+the kernels' durations are read from per-call HIP events after the region.
+
+After the timed region the same process measures time-to-image, the second half of the metric, as a separate
+strong-scaling render: the configuration's full sample count (1000 for cfg4) split over the ranks, then reduce and
+resolve; reported with the set-up (scene construction, BVH build, upload) that precedes any render.
+
+The OBJ/JPG assets of the reference are not redistributable and are absent on the GPU box: procedural stand-ins of
+the same triangle counts, object-space extents and transform chains are used (ray-tracing_amd/scenes.py).
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
@@ -25,27 +33,41 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_FP64_VECTOR_TFLOPS = 78.6   # MI355X vector FP64 = half the 157.3 TFLOP/s FP32 vector peak
+PEAK_FP64_VECTOR_TFLOPS = 78.6   # MI355X vector FP64 with every instruction an FMA = half the 157.3 TFLOP/s FP32 vector peak
 PEAK_HBM_GBS = 8000.0
-PROFILE_PREFIX = "r1_v9_eight_waves_"  # rocprofv3 summaries of this round's kernel under profiles/
+
+# name -> (scene builder name, builder kwargs, frame size, samples of a step, samples of the finished image, CPU baseline samples, description)
+CONFIGS = {
+    "cfg1": ("sphere_room_deterministic", {}, 512, 1, 1, 1, "cfg1 sphere room, point light, hard shadows, mirror + refraction, no jitter"),
+    "cfg2": ("sphere_room", {}, 512, 100, 100, 100, "cfg2 sphere room, area light, indirect, random Fresnel, antialiasing"),
+    "cfg3": ("mesh_room", {"n_tris": 54320, "tex_size": 1024}, 512, 100, 100, 24, "cfg3 textured mesh (54 320-triangle stand-in for the dog) on a mirror floor"),
+    "cfg4": ("battle", {}, 1024, 64, 1000, 12, "cfg4 battle scene (6 spheres + 12 procedural stand-in meshes, textures, DoF sigma 0.01)"),
+    "cfg5": ("stress", {}, 2048, 64, 256, 2, "cfg5 synthetic stress (5 M-triangle mesh + 1000 spheres)"),
+}
 
 
 def algorithmic_flops(c, n_spheres):
-    """Reference-algorithm flops of a counted run (add/sub/mul/div/sqrt/compare = 1; cos/sin/log/pow are
-    counted separately as transcendentals): per ray n_spheres*20 + 25 for the sphere that is hit,
-    24 per box test, 54 per triangle test; per path 60 for the camera sample; 150 per diffuse vertex,
-    40 per specular vertex."""
+    """Flops of a counted run (add/sub/mul/div/sqrt/compare = 1; cos/sin/log are counted separately as
+    transcendentals): per ray n_spheres*20 + 25 for the sphere that is hit, 24 per box test, 54 per triangle
+    test; per path 60 for the camera sample; 150 per diffuse vertex, 40 per specular vertex."""
     flops = (c["rays"] * (n_spheres * 20 + 25) + c["box_tests"] * 24 + c["tris"] * 54 + c["paths"] * 60 +
              c["diffuse"] * 150 + c["specular"] * 40)
     transc = c["paths"] * 8 + c["diffuse"] * 4
     return flops, transc
 
 
-def algorithmic_bytes(c, node_bytes=128):
-    """node_bytes per BVH record visited (128 B = two FP64 boxes + child links, what the algorithm as the
-    reference states it reads; the kernel's own records are 64 B with float boxes), 80 B per triangle
-    tested, 128 B of attributes per mesh hit (upper bound: one per mesh call), 24 B accumulate per path."""
+def algorithmic_bytes(c, node_bytes):
+    """node_bytes per BVH record visited, 80 B per triangle tested, 128 B of attributes per mesh hit (upper bound: one
+    per mesh call), 24 B accumulate per path"""
     return c["nodes"] * node_bytes + c["tris"] * 80 + c["mesh_calls"] * 128 + c["paths"] * 24
+
+
+def lib_sha16(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -53,10 +75,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp-step", type=int, default=64, help="samples per pixel per rank per step (one kernel launch up to 64)")
-    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--config", default="cfg4", choices=sorted(CONFIGS))
+    ap.add_argument("--spp-step", type=int, default=0, help="samples per pixel per rank per step (default: the configuration's; one kernel launch per 64)")
+    ap.add_argument("--size", type=int, default=0, help="frame size (default: the configuration's)")
+    ap.add_argument("--total-spp", type=int, default=0, help="samples of the time-to-image render, split over the ranks (default: the configuration's)")
+    ap.add_argument("--no-time-to-image", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=12, help="samples per pixel of the CPU baseline's bounded sample (12 spp = about 15 s on 16 cores)")
+    ap.add_argument("--cpu-spp", type=int, default=0, help="samples per pixel of the CPU baseline's bounded sample (default: the configuration's, 10-20 s of CPU work)")
     ap.add_argument("--out-png", default="")
     args = ap.parse_args()
 
@@ -69,7 +94,6 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit(2)
 
-    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -87,14 +111,25 @@ def main():
 
     rta = importlib.import_module("ray-tracing_amd")
     scenes = importlib.import_module("ray-tracing_amd.scenes")
+    parallel = importlib.import_module("ray-tracing_amd.parallel")
 
-    W = H = args.size
-    t0 = time.time()
-    scene, cam, flags, meta = scenes.battle(W=W)
+    builder, kw, size, spp_step, spp_image, cpu_spp, what = CONFIGS[args.config]
+    W = H = args.size or size
+    spp_step = args.spp_step or spp_step
+    spp_image = args.total_spp or spp_image
+    cpu_spp = args.cpu_spp or cpu_spp
+
+    # ---- set-up: what precedes any render (the reference's own 12 s @ 1 spp, README.md:129, includes it) ----
+    t0 = time.perf_counter()
+    out = getattr(scenes, builder)(W=W, **kw)   # scene construction: procedural meshes, transforms, buildBVH per mesh
+    scene, cam, flags = out[0], out[1], out[2]
+    t1 = time.perf_counter()
     r = rta.Renderer(local_rank)
-    r.upload(scene)
+    t2 = time.perf_counter()
+    r.upload(scene)                              # flatten + derived trees + copy to HBM
+    t3 = time.perf_counter()
+    setup = {"scene_build_s": round(t1 - t0, 3), "context_s": round(t2 - t1, 3), "upload_s": round(t3 - t2, 3), "total_s": round(t3 - t0, 3)}
     info = scene.flat_info()
-    setup_s = time.time() - t0
 
     accum = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
     acc_ptr = accum.data_ptr()
@@ -107,8 +142,8 @@ def main():
 
     def step(index):
         # global sample indices of this rank in this step: disjoint over (step, rank)
-        off = (index * world + rank) * args.spp_step
-        r.render(cam, rta.make_params(W, H, args.spp_step, spp_offset=off, flags=flags), acc_ptr)
+        off = parallel.shard_offset(index, world, rank, spp_step)
+        r.render(cam, rta.make_params(W, H, spp_step, spp_offset=off, flags=flags), acc_ptr)
 
     for w in range(args.warmup):
         step(w)
@@ -119,83 +154,112 @@ def main():
         dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize()
     accum.zero_()
+    r.render_time_ms(reset=True)
     barrier()
 
-    kernel_ms, kernel_launches = 0.0, 0
     t_start = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k)
-        if rank == 0:  # HIP-event time of this step's kernels on the render stream (waits for them)
-            ms, nl = r.last_render_ms()
-            kernel_ms += ms
-            kernel_launches += nl
     r.sync()
     if world > 1:
         dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize()  # the resolve below runs on the renderer's own stream: the sum must have landed
     image = None
     if rank == 0:
-        image = r.resolve(W, H, args.spp_step * args.steps * world, acc_ptr)
+        image = r.resolve(W, H, spp_step * args.steps * world, acc_ptr)
     barrier()
     elapsed = time.perf_counter() - t_start
+    kernel_ms, kernel_launches = r.render_time_ms(reset=True)  # HIP events around every step's kernels, on the render stream
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
-
-    paths_total = float(W) * H * args.spp_step * args.steps * world
+    paths_total = float(W) * H * spp_step * args.steps * world
     value = paths_total / elapsed / 1e6
 
+    # ---- time-to-image: the configuration's full sample count, split over the ranks (strong scaling) ----
+    tti = None
+    if not args.no_time_to_image:
+        lo, hi = parallel.split_samples(spp_image, rank, world)
+        accum.zero_()
+        barrier()
+        ta = time.perf_counter()
+        if hi > lo:
+            r.render(cam, rta.make_params(W, H, hi - lo, spp_offset=lo, flags=flags), acc_ptr)
+        r.sync()
+        if world > 1:
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+        if rank == 0:
+            image = r.resolve(W, H, spp_image, acc_ptr)
+        barrier()
+        tb = time.perf_counter() - ta
+        tm = torch.tensor([tb, setup["total_s"]], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        tb, su = float(tm[0].item()), float(tm[1].item())
+        png_s = None
+        if rank == 0 and args.out_png:
+            tp = time.perf_counter()
+            rta.write_png(args.out_png, image)
+            png_s = round(time.perf_counter() - tp, 3)
+        tti = {"spp": spp_image, "render_reduce_resolve_s": round(tb, 4), "setup_s": round(su, 3), "total_s": round(tb + su, 3),
+               "Mpaths_per_s": round(float(W) * H * spp_image / tb / 1e6, 2), "png_write_s": png_s,
+               "note": "set-up = scene construction (procedural stand-in meshes, transforms, buildBVH per mesh) + context + rt_upload_scene, max over ranks; "
+                       "render = %d samples per pixel split over %d rank(s), reduce to rank 0, tone map, image in host memory" % (spp_image, world)}
+
     if rank == 0:
-        # counted runs (separate, untimed). "Algorithmic" work is counted under the REFERENCE's traversal
-        # semantics (every node whose box the ray's line crosses, RT_F_NO_PRUNE) so that the figure does not
-        # depend on this implementation; the work the default (pruned, any-hit shadow) traversal really does
-        # is reported beside it.
+        # counted runs (separate, untimed): the work the kernel really does ("own": the default pruned traversal with
+        # any-hit shadow rays, on the reference's trees - the filter tree visits fewer records still) and the work of
+        # the algorithm as the reference states it (every node whose box the ray's line crosses, RT_F_NO_PRUNE).
         cnt_spp = 2
         scratch = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
         counted = {}
-        for label, extra in (("reference", rta.RT_F_NO_PRUNE), ("gpu", 0)):
+        for label, extra in (("reference", rta.RT_F_NO_PRUNE), ("own", 0)):
             r.reset_counters()
             r.render(cam, rta.make_params(W, H, cnt_spp, spp_offset=0, flags=flags | rta.RT_F_COUNTERS | extra), scratch.data_ptr())
             r.sync()
             counted[label] = r.counters()
-        c = counted["reference"]
-        g = counted["gpu"]
-        flops, transc = algorithmic_flops(c, info["n_spheres"])
-        flops_per_path = flops / c["paths"]
-        bytes_per_path = algorithmic_bytes(c) / c["paths"]
-        gpu_flops_per_path = algorithmic_flops(g, info["n_spheres"])[0] / g["paths"]
-        gpu_bytes_per_path = algorithmic_bytes(g, node_bytes=64) / g["paths"]
-        paths_per_launch = float(W) * H * args.spp_step * args.steps / max(1, kernel_launches)
+        c, g = counted["reference"], counted["own"]
+        paths_per_launch = float(W) * H * spp_step * args.steps / max(1, kernel_launches)
         avg_launch_s = kernel_ms / 1e3 / max(1, kernel_launches)
-        achieved_tflops = flops_per_path * paths_per_launch / avg_launch_s / 1e12
-        roofline = {"bound": "valu_fp64", "achieved": round(achieved_tflops, 4), "peak": PEAK_FP64_VECTOR_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved_tflops / PEAK_FP64_VECTOR_TFLOPS, 5), "traffic": None,
-                    "kernel": "rt_render_kernel<false, true>", "avg_launch_ms": round(avg_launch_s * 1e3, 3), "launches": kernel_launches,
-                    "algorithmic_flops_per_path": round(flops_per_path, 1), "transcendentals_per_path": round(transc / c["paths"], 2),
-                    "algorithmic_bytes_per_path": round(bytes_per_path, 1),
-                    "hbm_side": {"achieved_GBs": round(bytes_per_path * paths_per_launch / avg_launch_s / 1e9, 2), "peak_GBs": PEAK_HBM_GBS,
-                                 "frac": round(bytes_per_path * paths_per_launch / avg_launch_s / 1e9 / PEAK_HBM_GBS, 4)},
-                    "rays_per_path": round(c["rays"] / c["paths"], 3), "nodes_per_path": round(c["nodes"] / c["paths"], 2),
-                    "tris_per_path": round(c["tris"] / c["paths"], 2),
-                    "gpu_own_work": {"nodes_per_path": round(g["nodes"] / g["paths"], 2), "tris_per_path": round(g["tris"] / g["paths"], 2),
-                                     "flops_per_path": round(gpu_flops_per_path, 1), "bytes_per_path": round(gpu_bytes_per_path, 1),
-                                     "TFLOPs": round(gpu_flops_per_path * paths_per_launch / avg_launch_s / 1e12, 4),
-                                     "GBs": round(gpu_bytes_per_path * paths_per_launch / avg_launch_s / 1e9, 2)}}
-        # HBM-side bytes per launch: not collectable inside this process (PMC needs rocprofv3 around it); taken from the
-        # committed counter pass of this same command, FETCH_SIZE (KB, 64 B per L2 fabric read request) doubled as the
-        # gfx950 correction for 128-byte requests prescribes. Null when the summary is absent.
+        own_flops = algorithmic_flops(g, info["n_spheres"])[0] / g["paths"]
+        own_bytes = algorithmic_bytes(g, node_bytes=64) / g["paths"]       # the kernel's records: 64 B with float boxes
+        ref_flops, ref_transc = algorithmic_flops(c, info["n_spheres"])
+        ref_flops /= c["paths"]
+        ref_bytes = algorithmic_bytes(c, node_bytes=128) / c["paths"]      # two FP64 boxes + links, as the reference holds them
+        own_tflops = own_flops * paths_per_launch / avg_launch_s / 1e12
+        ref_tflops = ref_flops * paths_per_launch / avg_launch_s / 1e12
+        own_gbs = own_bytes * paths_per_launch / avg_launch_s / 1e9
+        kname = "rt_render_spheres_kernel<false>" if info["n_spheres"] > 64 else ("rt_render_kernel<false, true>" if flags == 0 else "rt_render_kernel<false, false>")
+        roofline = {
+            "bound": "valu_fp64", "achieved": round(own_tflops, 4), "peak": PEAK_FP64_VECTOR_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(own_tflops / PEAK_FP64_VECTOR_TFLOPS, 5), "own_work_frac": round(own_tflops / PEAK_FP64_VECTOR_TFLOPS, 5),
+            "frac_of_fma_less_peak": round(own_tflops / (PEAK_FP64_VECTOR_TFLOPS / 2), 5),
+            "traffic": None, "kernel": kname, "avg_launch_ms": round(avg_launch_s * 1e3, 3), "launches": kernel_launches,
+            "paths_per_launch": paths_per_launch,
+            "definition": "achieved = flops the kernel's own traversal executes (counted variant of the same kernel) per launch / mean launch "
+                          "duration (HIP events on the render stream over the timed region); no FMA contraction (-ffp-contract=off), so the "
+                          "ceiling for this instruction mix is peak / 2",
+            "own_work": {"flops_per_path": round(own_flops, 1), "bytes_per_path": round(own_bytes, 1), "nodes_per_path": round(g["nodes"] / g["paths"], 2),
+                         "tris_per_path": round(g["tris"] / g["paths"], 2), "requested_GBs": round(own_gbs, 2),
+                         "note": "bytes the traversal asks for (records, triangles, attributes), served mostly by L1/L2: compare `traffic` (HBM side) where a counter pass exists"},
+            "reference_semantics": {"flops_per_path": round(ref_flops, 1), "transcendentals_per_path": round(ref_transc / c["paths"], 2),
+                                    "bytes_per_path": round(ref_bytes, 1), "nodes_per_path": round(c["nodes"] / c["paths"], 2),
+                                    "tris_per_path": round(c["tris"] / c["paths"], 2), "TFLOPs_equivalent": round(ref_tflops, 4),
+                                    "frac_equivalent": round(ref_tflops / PEAK_FP64_VECTOR_TFLOPS, 5),
+                                    "note": "the unpruned reference algorithm's flops divided by this kernel's time: a speed-up-inclusive figure, not a utilisation"},
+            "rays_per_path": round(c["rays"] / c["paths"], 3)}
+        # HBM-side bytes per launch: not collectable inside this process (PMC needs rocprofv3 around it). Taken from the
+        # committed counter pass of this same command ONLY if that pass was made with this very library build (hash stored
+        # in the summary); FETCH_SIZE is in KB of 64 B requests, doubled for gfx950's 128-byte requests. Null otherwise.
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", PROFILE_PREFIX + "mem2.json")))
-            kk = [k for k in pm if "rt_render_kernel<false, true>" in k][0]
-            roofline["traffic"] = round(pm[kk]["FETCH_SIZE"] * 1024.0 * 2.0 / pm[kk]["dispatches"], 1)
-            roofline["traffic_note"] = ("bytes per launch of 1024x1024x64 paths from profiles/%smem2.json (rocprofv3 --pmc FETCH_SIZE of "
-                                        "`bench.py --steps 2 --warmup 1 --no-cpu-baseline`, 64 spp per launch), x2 gfx950 correction; "
-                                        "algorithmic bytes per launch = %.4g" % (PROFILE_PREFIX, bytes_per_path * paths_per_launch))
-            if args.spp_step != 64 or W != 1024:
-                roofline["traffic"] = None  # the committed counter pass is of the default launch size only
-                roofline["traffic_note"] = "no counter pass for this launch size"
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r2_%s_mem2.json" % args.config)))
+            if pm.get("lib_sha16") == lib_sha16(rta.LIB_PATH) and pm.get("spp_step") == spp_step and pm.get("size") == W:
+                kk = [k for k in pm["kernels"] if k.startswith(kname.split("<")[0])][0]
+                roofline["traffic"] = round(pm["kernels"][kk]["FETCH_SIZE"] * 1024.0 * 2.0 / pm["kernels"][kk]["dispatches"], 1)
+                roofline["traffic_note"] = "HBM-side fetch bytes per launch from profiles/r2_%s_mem2.json (same library build), x2 gfx950 correction" % args.config
         except (OSError, KeyError, IndexError, ValueError, ZeroDivisionError):
             pass
         import ctypes
@@ -208,30 +272,28 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             from oracle import bindings as ob
             t1 = time.time()
-            orc = ob.OracleScene(scenes.export_objects(scene), scene.I, scene.L)
+            orc = ob.OracleScene(scenes.export_objects(scene), scene.I, scene.L, math="libm")  # as the reference: the host's libm
             threads = min(ob.orc.orc_max_threads(), int(os.environ.get("OMP_NUM_THREADS", "0")) or 1 << 30)
-            p = rta.make_params(W, H, args.cpu_spp, flags=flags)
+            p = rta.make_params(W, H, cpu_spp, flags=flags)
             t2 = time.time()
             orc.render(cam, p, n_threads=threads)
             dt = time.time() - t2
-            cpu = {"value": round(W * H * args.cpu_spp / dt / 1e6, 4), "unit": "Mpaths/s", "cores": threads, "kind": "port",
-                   "sample": "same scene and frame, %d spp (%.1f s of CPU work on %d OpenMP threads, schedule(dynamic,1) rows); "
-                             "oracle/ref_cpu.cpp with the counter-based RNG" % (args.cpu_spp, dt, threads),
+            cpu = {"value": round(W * H * cpu_spp / dt / 1e6, 4), "unit": "Mpaths/s", "cores": threads, "kind": "port",
+                   "sample": "same scene and frame, %d of %d spp (%.1f s of CPU work on %d OpenMP threads, schedule(dynamic,1) rows); "
+                             "oracle/ref_cpu.cpp with the counter-based RNG (the reference's one shared engine makes its threads wait for each other)" % (cpu_spp, spp_image, dt, threads),
                    "setup_s": round(t2 - t1, 2)}
-        if args.out_png and image is not None:
-            rta.write_png(args.out_png, image)
-        out = {"metric": "Mpaths/s (whole node) final scene 1024x1024", "value": round(value, 3), "unit": "Mpaths/s",
+        out = {"metric": "Mpaths/s (whole node) final scene 1024x1024" if args.config == "cfg4" else "Mpaths/s (whole node) %s %dx%d" % (args.config, W, H),
+               "value": round(value, 3), "unit": "Mpaths/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": "cfg4 battle scene (6 spheres + 12 procedural stand-in meshes, %d triangles, %d BVH records, "
-                                      "textures, DoF sigma 0.01), %dx%d, %d spp per rank per step; time-to-image at 1000 spp "
-                                      "extrapolates to %.2f s on this many GPUs" % (info["n_tris"], info["n_nodes"], W, H, args.spp_step,
-                                                                                      1000.0 * W * H / (value * 1e6)),
-                          "spp_per_step": args.spp_step, "parallelism": "spp-sharded x%d + %s reduce(sum) of the f64 accumulator" % (world, "RCCL" if backend == "nccl" else backend),
+               "config": {"workload": "%s, %d triangles, %d BVH records, %d spheres, %dx%d, %d spp per rank per step" % (what, info["n_tris"], info["n_nodes"], info["n_spheres"], W, H, spp_step),
+                          "name": args.config, "spp_per_step": spp_step,
+                          "parallelism": "spp-sharded x%d + %s reduce(sum) of the f64 accumulator" % (world, "RCCL" if backend == "nccl" else backend),
                           "scene_bytes_hbm": info["bytes"], "scene_bytes_device": sizes[0], "traversal_records": sizes[1],
                           "filter_tree_records": sizes[2], "waves_per_cu": min(occ_b.value, 8), "lds_bytes_per_wave": occ_l.value,
-                          "setup_s": round(setup_s, 2)},
+                          "setup": setup},
                "rays_per_s": round(value * 1e6 * c["rays"] / c["paths"], 1),
+               "time_to_image": tti,
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out))
     if world > 1:

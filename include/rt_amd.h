@@ -238,6 +238,15 @@ int rt_accum_upload(rt_ctx *ctx, const double *host_in, int64_t n_doubles);
 /* Device address of the context's own accumulator (NULL before rt_accum_clear). */
 double *rt_accum_device_ptr(rt_ctx *ctx);
 
+/* Multi-GPU within one process: dst's own accumulator += src's own accumulator (same W, H), where the two contexts may
+ * sit on different GPUs (peer copy over xGMI into a staging buffer of dst, then an add kernel on dst's stream) or share
+ * one. This is the one exchange step of samples-per-pixel sharding - each context renders its own range of sample
+ * indices (rt_params.spp_offset) of every pixel, the reference's "rows in parallel" (raytracer.cpp:1456) turned into
+ * "samples in parallel" - for callers that drive several GPUs from threads of one process; processes-per-GPU callers
+ * sum with RCCL instead. Waits for src's renders, returns when the sum is in dst. Adding the contexts in a fixed order
+ * gives run-to-run identical bits. */
+int rt_accum_add(rt_ctx *dst, rt_ctx *src);
+
 /* Replaces raytracer.cpp:1488-1501: colour/spp_total, pow(.,0.45), min(255,.),
  * truncation to unsigned char, vertical flip. accum = DEVICE pointer or NULL
  * (own accumulator); rgb8_host receives W*H*3 bytes. Synchronous. */
@@ -287,6 +296,11 @@ int rt_reset_counters(rt_ctx *ctx);
  * rt_render call, measured with HIP events on the context's stream; waits
  * for them. n_launches (may be NULL) receives how many kernels that was. */
 int rt_last_render_ms(rt_ctx *ctx, double *ms, int32_t *n_launches);
+
+/* The same over many calls: total duration in milliseconds of the render kernels of every rt_render call since the last
+ * reset (each call has its own pair of HIP events on the context's stream, so nothing waits between the calls; this
+ * function waits for the last of them), and how many kernels that was. reset != 0 starts a new total. */
+int rt_render_time_ms(rt_ctx *ctx, double *ms_total, int32_t *n_launches, int32_t reset);
 
 /* The HIP stream of the context as a void* (hipStream_t), for callers that
  * want to order their own work after a render. */

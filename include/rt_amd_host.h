@@ -55,6 +55,10 @@ int rth_scene_add_sphere(rth_scene *s, const double O[3], double R, const double
 int rth_scene_add_mesh(rth_scene *s, rth_mesh *m); /* borrowed: the mesh must outlive the scene */
 /* flatten + rt_upload_scene; flat_bytes (may be NULL) = bytes copied to HBM */
 int rth_scene_upload(rth_scene *s, rt_ctx *ctx, int64_t *flat_bytes);
+/* rt::render on several GPUs from one process (one host thread and one context per entry of `devices`; a device may be
+ * listed twice): the p->spp samples of every pixel are split over the entries, summed on the first (rt_accum_add) and
+ * tone-mapped there; rgb8 receives W*H*3 bytes. Replaces the OpenMP pixel loop raytracer.cpp:1456-1503. */
+int rth_scene_render_devices(rth_scene *s, const rt_camera *cam, const rt_params *p, const int32_t *devices, int32_t n_devices, uint8_t *rgb8);
 int rth_scene_flat_info(rth_scene *s, int64_t *n_spheres, int64_t *n_meshes, int64_t *n_nodes, int64_t *n_tris, int64_t *bytes);
 
 /* camera basis as main() builds it (raytracer.cpp:1441-1453) and the literals of the render loop */

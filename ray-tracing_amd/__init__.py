@@ -53,12 +53,12 @@ class rt_counters(C.Structure):
 
 # every symbol include/rt_amd.h and include/rt_amd_host.h declare
 RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_render", "rt_render_static", "rt_sync", "rt_accum_clear",
-              "rt_accum_download", "rt_accum_upload", "rt_accum_device_ptr", "rt_resolve", "rt_intersect_rays", "rt_sample_radiance", "rt_sample_trace",
-              "rt_get_counters", "rt_reset_counters", "rt_last_render_ms", "rt_stream", "rt_version", "rt_build_bvh"]
+              "rt_accum_download", "rt_accum_upload", "rt_accum_device_ptr", "rt_accum_add", "rt_resolve", "rt_intersect_rays", "rt_sample_radiance", "rt_sample_trace",
+              "rt_get_counters", "rt_reset_counters", "rt_last_render_ms", "rt_render_time_ms", "rt_stream", "rt_version", "rt_build_bvh"]
 RTH_SYMBOLS = ["rth_last_error", "rth_mesh_create", "rth_mesh_destroy", "rth_mesh_read_obj", "rth_mesh_load_texture",
                "rth_mesh_add_texture", "rth_mesh_set_raw", "rth_mesh_op", "rth_mesh_build_bvh", "rth_mesh_build_bvh_device", "rth_mesh_sizes",
                "rth_mesh_get", "rth_mesh_bvh_dump", "rth_scene_create", "rth_scene_destroy", "rth_scene_add_sphere",
-               "rth_scene_add_mesh", "rth_scene_upload", "rth_scene_flat_info", "rth_camera_make", "rth_params_default",
+               "rth_scene_add_mesh", "rth_scene_upload", "rth_scene_render_devices", "rth_scene_flat_info", "rth_camera_make", "rth_params_default",
                "rth_write_png", "rth_write_execution_time"]
 
 _vp, _i32, _i64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
@@ -82,6 +82,7 @@ _sig("rt_accum_clear", C.c_int, _vp, _i32, _i32)
 _sig("rt_accum_download", C.c_int, _vp, _vp, _i64)
 _sig("rt_accum_upload", C.c_int, _vp, _vp, _i64)
 _sig("rt_accum_device_ptr", _vp, _vp)
+_sig("rt_accum_add", C.c_int, _vp, _vp)
 _sig("rt_resolve", C.c_int, _vp, _vp, _i32, _i32, _dbl, _vp)
 _sig("rt_intersect_rays", C.c_int, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp)
 _sig("rt_sample_radiance", C.c_int, _vp, C.POINTER(rt_camera), C.POINTER(rt_params), _vp, _i64, _vp)
@@ -89,6 +90,7 @@ _sig("rt_sample_trace", C.c_int, _vp, C.POINTER(rt_camera), C.POINTER(rt_params)
 _sig("rt_get_counters", C.c_int, _vp, C.POINTER(rt_counters))
 _sig("rt_reset_counters", C.c_int, _vp)
 _sig("rt_last_render_ms", C.c_int, _vp, _pd, C.POINTER(_i32))
+_sig("rt_render_time_ms", C.c_int, _vp, _pd, C.POINTER(_i32), _i32)
 _sig("rt_stream", _vp, _vp)
 _sig("rt_version", C.c_char_p)
 _sig("rth_last_error", C.c_char_p)
@@ -110,6 +112,7 @@ _sig("rth_scene_destroy", None, _vp)
 _sig("rth_scene_add_sphere", C.c_int, _vp, _pd, _dbl, _pd, C.c_int, C.c_int)
 _sig("rth_scene_add_mesh", C.c_int, _vp, _vp)
 _sig("rth_scene_upload", C.c_int, _vp, _vp, C.POINTER(_i64))
+_sig("rth_scene_render_devices", C.c_int, _vp, C.POINTER(rt_camera), C.POINTER(rt_params), _vp, _i32, _vp)
 _sig("rth_scene_flat_info", C.c_int, _vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64))
 _sig("rth_camera_make", C.c_int, _pd, _dbl, _dbl, _dbl, _i32, _dbl, _dbl, _dbl, C.POINTER(rt_camera))
 _sig("rth_params_default", C.c_int, _i32, _i32, _i32, C.POINTER(rt_params))
@@ -347,6 +350,10 @@ class Renderer:
         acc = np.ascontiguousarray(acc, np.float64)
         self._check(lib.rt_accum_upload(self._h, _ptr(acc), acc.size))
 
+    def accum_add(self, other):
+        """own accumulator += other's own accumulator (another context, on this GPU or another one)"""
+        self._check(lib.rt_accum_add(self._h, other._h))
+
     def accum_device_ptr(self):
         return lib.rt_accum_device_ptr(self._h)
 
@@ -390,6 +397,12 @@ class Renderer:
         self._check(lib.rt_last_render_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def render_time_ms(self, reset=True):
+        """(total milliseconds, kernel launches) of the render calls since the last reset; waits for them"""
+        ms, n = C.c_double(), _i32()
+        self._check(lib.rt_render_time_ms(self._h, C.byref(ms), C.byref(n), 1 if reset else 0))
+        return ms.value, n.value
+
     def stream(self):
         return lib.rt_stream(self._h)
 
@@ -416,6 +429,19 @@ def render(scene, cam, W, H, spp, seed=10, flags=0, device=0):
         return r.resolve(W, H, spp)
     finally:
         r.close()
+
+
+def render_devices(scene, cam, W, H, spp, devices, seed=10, flags=0):
+    """rt::render over several GPUs of one process: the samples split over `devices`, summed on the first, tone-mapped"""
+    h = scene._build_handle()
+    try:
+        out = np.empty((H, W, 3), np.uint8)
+        dv = np.ascontiguousarray(devices, np.int32)
+        p = make_params(W, H, spp, seed=seed, flags=flags)
+        _host_check(lib.rth_scene_render_devices(h, C.byref(cam), C.byref(p), _ptr(dv), len(dv), _ptr(out)))
+        return out
+    finally:
+        lib.rth_scene_destroy(h)
 
 
 def version():

@@ -12,6 +12,7 @@
 #include <chrono>
 #include <thread>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "rt_amd.h"
@@ -168,6 +169,12 @@ __global__ void rt_units_add_kernel(double *accum, const double *unit_sums, int 
     accum[at] = a;
 }
 
+/* dst += src over n doubles: the sum of two devices' sample ranges (rt_accum_add) */
+__global__ void rt_accum_add_kernel(double *dst, const double *src, int64_t n) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) dst[t] = dst[t] + src[t];
+}
+
 /* tone[k], k = 1 .. 255: the smallest double v with pow(v, 0.45) >= k under the HOST's libm (tone_thresholds below), so
  * the byte (unsigned char)std::min(255., pow(v, 0.45)) of raytracer.cpp:1499-1501 is the number of thresholds not above
  * v - the same byte as the CPU program computes, whatever the device's own pow would round to at a boundary. A NaN or
@@ -201,9 +208,13 @@ __global__ void rt_resolve_kernel(const double *accum, int W, int H, double spp,
 struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr; /* around the launches of the last rt_render call */
     bool timed = false;
     int last_launches = 0;
+    /* rt_render_time_ms: event pairs of the calls since the last reset (created on demand, reused after a reset) */
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    int launches_since_reset = 0;
     std::string err;
     /* scene */
     bool have_scene = false;
@@ -223,6 +234,8 @@ struct rt_ctx {
     double *d_tone = nullptr;    /* 256 tone-map thresholds (tone_thresholds) */
     uint8_t *d_rgb = nullptr;    /* rt_resolve's device image, kept and grown on demand */
     size_t d_rgb_bytes = 0;
+    double *d_peer = nullptr;    /* rt_accum_add: another context's accumulator, copied here before it is added */
+    size_t d_peer_bytes = 0;
     unsigned char *static_scratch = nullptr; /* this device's copy of `scratch` (hipGetSymbolAddress at rt_create) */
     int n_cus = 256;
     int waves_per_cu = 8;
@@ -358,9 +371,11 @@ void rt_destroy(rt_ctx *c) {
     if (c->d_overflow) (void)hipFree(c->d_overflow);
     if (c->d_next_slot) (void)hipFree(c->d_next_slot);
     if (c->d_tone) (void)hipFree(c->d_tone);
+    if (c->d_peer) (void)hipFree(c->d_peer);
     if (c->d_rgb) (void)hipFree(c->d_rgb);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -984,7 +999,17 @@ static int render_impl(rt_ctx *c, const rt_camera *cam, const rt_params *p, doub
     }
     c->last_launches = 0;
     c->timed = false;
+    hipEvent_t span0 = c->ev0, span1 = c->ev1;
+    if (!use_static && c->ev_used < 4096) { /* a pair of this call's own, so that a caller can add up many calls without waiting between them */
+        if (c->ev_used == c->ev_pool.size()) {
+            hipEvent_t a = nullptr, b = nullptr;
+            if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) c->ev_pool.emplace_back(a, b);
+            else { if (a) (void)hipEventDestroy(a); (void)hipGetLastError(); }
+        }
+        if (c->ev_used < c->ev_pool.size()) { span0 = c->ev_pool[c->ev_used].first; span1 = c->ev_pool[c->ev_used].second; c->ev_used++; }
+    }
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (span0 != c->ev0) HIPCHK(c, hipEventRecord(span0, c->stream));
     /* persistent waves: as many as stay resident, each pulling 64-pixel tiles */
     for (int k = 0; k < p->spp; k += kSppPerLaunch) {
         const int nk = (p->spp - k < kSppPerLaunch) ? (p->spp - k) : kSppPerLaunch;
@@ -1031,8 +1056,10 @@ static int render_impl(rt_ctx *c, const rt_camera *cam, const rt_params *p, doub
         }
         c->last_launches++;
     }
+    if (span1 != c->ev1) HIPCHK(c, hipEventRecord(span1, c->stream));
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->timed = true;
+    if (span1 != c->ev1) c->launches_since_reset += c->last_launches;
     return RT_OK;
 }
 
@@ -1054,6 +1081,21 @@ int rt_last_render_ms(rt_ctx *c, double *ms, int32_t *n_launches) {
     HIPCHK(c, hipEventElapsedTime(&f, c->ev0, c->ev1));
     *ms = f;
     if (n_launches) *n_launches = c->last_launches;
+    return RT_OK;
+}
+
+int rt_render_time_ms(rt_ctx *c, double *ms_total, int32_t *n_launches, int32_t reset) {
+    if (!c) return RT_E_INVALID;
+    double sum = 0;
+    for (size_t k = 0; k < c->ev_used; k++) {
+        HIPCHK(c, hipEventSynchronize(c->ev_pool[k].second));
+        float f = 0;
+        HIPCHK(c, hipEventElapsedTime(&f, c->ev_pool[k].first, c->ev_pool[k].second));
+        sum += f;
+    }
+    if (ms_total) *ms_total = sum;
+    if (n_launches) *n_launches = c->launches_since_reset;
+    if (reset) { c->ev_used = 0; c->launches_since_reset = 0; }
     return RT_OK;
 }
 
@@ -1090,6 +1132,33 @@ int rt_accum_upload(rt_ctx *c, const double *host_in, int64_t n) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(c->accum, host_in, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_accum_add(rt_ctx *dst, rt_ctx *src) {
+    if (!dst || !src) return RT_E_INVALID;
+    if (dst == src) return fail(dst, RT_E_INVALID, "rt_accum_add: a context cannot be added to itself");
+    if (!dst->accum || !src->accum || dst->accW != src->accW || dst->accH != src->accH)
+        return fail(dst, RT_E_STATE, "rt_accum_add: both contexts need their own accumulator of the same size (rt_accum_clear)");
+    const int64_t n = (int64_t)dst->accW * dst->accH * 3;
+    const size_t nb = (size_t)n * sizeof(double);
+    /* the source's renders must have finished before its accumulator is read from another stream */
+    HIPCHK(dst, hipSetDevice(src->device));
+    HIPCHK(dst, hipStreamSynchronize(src->stream));
+    HIPCHK(dst, hipSetDevice(dst->device));
+    if (dst->d_peer_bytes < nb) {
+        HIPCHK(dst, hipStreamSynchronize(dst->stream));
+        if (dst->d_peer) (void)hipFree(dst->d_peer);
+        dst->d_peer = nullptr;
+        dst->d_peer_bytes = 0;
+        if (hipMalloc((void **)&dst->d_peer, nb) != hipSuccess) return fail(dst, RT_E_NOMEM, "rt_accum_add: staging buffer allocation failed");
+        dst->d_peer_bytes = nb;
+    }
+    /* over xGMI when the two contexts sit on different GPUs, a device-to-device copy when they share one */
+    HIPCHK(dst, hipMemcpyPeerAsync(dst->d_peer, dst->device, src->accum, src->device, nb, dst->stream));
+    hipLaunchKernelGGL(rt_accum_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, dst->stream, dst->accum, dst->d_peer, n);
+    HIPCHK(dst, hipGetLastError());
+    HIPCHK(dst, hipStreamSynchronize(dst->stream)); /* the caller may clear or destroy src as soon as this returns */
     return RT_OK;
 }
 

@@ -565,6 +565,48 @@ void render(const Scene &scene, const Camera &cam, const RenderParams &p, std::v
     r.render(cam, p, image);
 }
 
+void renderDevices(const rt_scene_desc &d, const rt_camera &cam, const rt_params &p, const int *devices, int n, uint8_t *rgb8) {
+    if (!devices || n <= 0 || !rgb8) throw std::runtime_error("renderDevices: empty device list or no image buffer");
+    std::vector<rt_ctx *> ctx((size_t)n, nullptr);
+    std::vector<std::string> err((size_t)n);
+    auto work = [&](int k) {
+        /* one host thread per device: create, upload, render this device's samples [lo, hi) of every pixel */
+        auto bad = [&](const char *what, rt_ctx *x) { err[(size_t)k] = std::string(what) + ": " + rt_last_error(x); };
+        if (rt_create(devices[k], &ctx[(size_t)k]) != RT_OK) { bad("rt_create", nullptr); return; }
+        rt_ctx *x = ctx[(size_t)k];
+        if (rt_upload_scene(x, &d) != RT_OK) { bad("rt_upload_scene", x); return; }
+        if (rt_accum_clear(x, p.W, p.H) != RT_OK) { bad("rt_accum_clear", x); return; }
+        rt_params rp = p;
+        const int64_t lo = (int64_t)p.spp * k / n, hi = (int64_t)p.spp * (k + 1) / n;
+        rp.spp = (int32_t)(hi - lo);
+        rp.spp_offset = p.spp_offset + (int32_t)lo;
+        if (rp.spp > 0 && rt_render(x, &cam, &rp, nullptr) != RT_OK) { bad("rt_render", x); return; }
+        if (rt_sync(x) != RT_OK) bad("rt_sync", x);
+    };
+    {
+        std::vector<std::thread> th;
+        for (int k = 1; k < n; k++) th.emplace_back(work, k);
+        work(0);
+        for (auto &t : th) t.join();
+    }
+    std::string first_err;
+    for (int k = 0; k < n && first_err.empty(); k++) first_err = err[(size_t)k];
+    for (int k = 1; k < n && first_err.empty(); k++) /* fixed order: the same bits from run to run */
+        if (rt_accum_add(ctx[0], ctx[(size_t)k]) != RT_OK) first_err = std::string("rt_accum_add: ") + rt_last_error(ctx[0]);
+    if (first_err.empty() && rt_resolve(ctx[0], nullptr, p.W, p.H, (double)p.spp, rgb8) != RT_OK) first_err = std::string("rt_resolve: ") + rt_last_error(ctx[0]);
+    for (rt_ctx *x : ctx) rt_destroy(x);
+    if (!first_err.empty()) throw std::runtime_error(first_err);
+}
+
+void render(const Scene &scene, const Camera &cam, const RenderParams &p, std::vector<uint8_t> &image, const std::vector<int> &devices) {
+    if (scene.objects.empty() || !dynamic_cast<const Sphere *>(scene.objects[0]))
+        throw std::runtime_error("render: objects[0] must be the light Sphere (raytracer.cpp:970)");
+    FlatScene fs;
+    flatten(scene, fs); /* once: every device gets the same arrays */
+    image.resize((size_t)p.W * p.H * 3);
+    renderDevices(fs.desc(), cam.pod(p.W), p.pod(), devices.data(), (int)devices.size(), image.data());
+}
+
 /* ---- image and timing output (raytracer.cpp:1505-1512) ------------------------------------------------------- */
 namespace {
 struct Crc32 {
@@ -787,6 +829,15 @@ int rth_scene_upload(rth_scene *s, rt_ctx *ctx, int64_t *flat_bytes) {
     }
 }
 /* flattening only (no device): sizes of the arrays rt_upload_scene would receive */
+int rth_scene_render_devices(rth_scene *s, const rt_camera *cam, const rt_params *p, const int32_t *devices, int32_t n_devices, uint8_t *rgb8) {
+    RTH_TRY({
+        if (!s || !cam || !p) throw std::runtime_error("rth_scene_render_devices: NULL argument");
+        rt::FlatScene fs;
+        rt::flatten(s->s, fs);
+        rt::renderDevices(fs.desc(), *cam, *p, devices, n_devices, rgb8);
+    })
+}
+
 int rth_scene_flat_info(rth_scene *s, int64_t *n_spheres, int64_t *n_meshes, int64_t *n_nodes, int64_t *n_tris, int64_t *bytes) {
     RTH_TRY({
         rt::FlatScene fs;

@@ -192,6 +192,16 @@ private:
 /* convenience: one call = what running the reference's main() does up to the PNG write */
 void render(const Scene &scene, const Camera &cam, const RenderParams &p, std::vector<uint8_t> &image, int device = 0);
 
+/* The same on several GPUs of this machine (the reference's one parallel construct, OpenMP threads over rows at
+ * raytracer.cpp:1456, becomes threads over GPUs): device d of `devices` gets its own context and copy of the scene and
+ * renders its share of the nbrays sample indices of every pixel on a host thread of its own; the accumulators are
+ * then added onto the first device in the order of the list (rt_accum_add: peer copies over xGMI) and resolved there.
+ * The image does not depend on the number of devices up to the order of these last additions. A device may be listed
+ * more than once (two contexts then share it). */
+void render(const Scene &scene, const Camera &cam, const RenderParams &p, std::vector<uint8_t> &image, const std::vector<int> &devices);
+/* the same for callers that hold the flattened scene and the PODs: p.spp samples from p.spp_offset on, rgb8 = W*H*3 bytes */
+void renderDevices(const rt_scene_desc &d, const rt_camera &cam, const rt_params &p, const int *devices, int n_devices, uint8_t *rgb8);
+
 /* The output step of main(), raytracer.cpp:1505-1512. writePNG stores an 8-bit RGB image (rows top to bottom, as
  * Renderer::render returns it) as a PNG file: the same pixels as the reference's stbi_write_png call, in an
  * uncompressed zlib stream (any decoder reads it; the encoder is this library's own). writeExecutionTime writes the

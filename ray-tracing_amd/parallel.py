@@ -13,6 +13,13 @@ def shard_offset(step, world, rank, spp_step):
     return (step * world + rank) * spp_step
 
 
+def split_samples(total, rank, world):
+    """strong scaling: the half-open range of global sample indices [lo, hi) that rank `rank` of `world` renders of an
+    image of `total` samples per pixel; the ranges of all ranks are disjoint, cover 0 .. total-1 and differ in length by
+    at most one (ranks beyond `total` get an empty range)"""
+    return total * rank // world, total * (rank + 1) // world
+
+
 def total_spp(steps, world, spp_step):
     return steps * world * spp_step
 
