@@ -46,11 +46,14 @@ CONFIGS = {
 }
 
 
-def algorithmic_flops(c, n_spheres):
+def algorithmic_flops(c, n_spheres, own=False):
     """Flops of a counted run (add/sub/mul/div/sqrt/compare = 1; cos/sin/log are counted separately as
     transcendentals): per ray n_spheres*20 + 25 for the sphere that is hit, 24 per box test, 54 per triangle
     test; per path 60 for the camera sample; 150 per diffuse vertex, 40 per specular vertex."""
-    flops = (c["rays"] * (n_spheres * 20 + 25) + c["box_tests"] * 24 + c["tris"] * 54 + c["paths"] * 60 +
+    sphere_work = c["rays"] * n_spheres * 20  # the algorithm as stated: every ray tests every sphere (raytracer.cpp:934-938)
+    if "sphere_tests" in c and own:           # the kernel's own work: the exact tests it did + the boxes of its sphere tree
+        sphere_work = c["sphere_tests"] * 20 + c["sphere_nodes"] * 24
+    flops = (sphere_work + c["rays"] * 25 + c["box_tests"] * 24 + c["tris"] * 54 + c["paths"] * 60 +
              c["diffuse"] * 150 + c["specular"] * 40)
     transc = c["paths"] * 8 + c["diffuse"] * 4
     return flops, transc
@@ -94,6 +97,7 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit(2)
 
+    import ctypes
     import torch
     import torch.distributed as dist
 
@@ -221,10 +225,13 @@ def main():
             r.render(cam, rta.make_params(W, H, cnt_spp, spp_offset=0, flags=flags | rta.RT_F_COUNTERS | extra), scratch.data_ptr())
             r.sync()
             counted[label] = r.counters()
+            dbg = (ctypes.c_uint64 * 22)()
+            rta.lib.rt_debug_stats(r._h, dbg)
+            counted[label]["sphere_tests"], counted[label]["sphere_nodes"] = int(dbg[20]), int(dbg[21])
         c, g = counted["reference"], counted["own"]
         paths_per_launch = float(W) * H * spp_step * args.steps / max(1, kernel_launches)
         avg_launch_s = kernel_ms / 1e3 / max(1, kernel_launches)
-        own_flops = algorithmic_flops(g, info["n_spheres"])[0] / g["paths"]
+        own_flops = algorithmic_flops(g, info["n_spheres"], own=True)[0] / g["paths"]
         own_bytes = algorithmic_bytes(g, node_bytes=64) / g["paths"]       # the kernel's records: 64 B with float boxes
         ref_flops, ref_transc = algorithmic_flops(c, info["n_spheres"])
         ref_flops /= c["paths"]
@@ -243,7 +250,8 @@ def main():
                           "duration (HIP events on the render stream over the timed region); no FMA contraction (-ffp-contract=off), so the "
                           "ceiling for this instruction mix is peak / 2",
             "own_work": {"flops_per_path": round(own_flops, 1), "bytes_per_path": round(own_bytes, 1), "nodes_per_path": round(g["nodes"] / g["paths"], 2),
-                         "tris_per_path": round(g["tris"] / g["paths"], 2), "requested_GBs": round(own_gbs, 2),
+                         "tris_per_path": round(g["tris"] / g["paths"], 2), "sphere_tests_per_ray": round(g["sphere_tests"] / max(1, g["rays"]), 2),
+                         "sphere_tree_nodes_per_ray": round(g["sphere_nodes"] / max(1, g["rays"]), 2), "requested_GBs": round(own_gbs, 2),
                          "note": "bytes the traversal asks for (records, triangles, attributes), served mostly by L1/L2: compare `traffic` (HBM side) where a counter pass exists"},
             "reference_semantics": {"flops_per_path": round(ref_flops, 1), "transcendentals_per_path": round(ref_transc / c["paths"], 2),
                                     "bytes_per_path": round(ref_bytes, 1), "nodes_per_path": round(c["nodes"] / c["paths"], 2),
@@ -262,7 +270,6 @@ def main():
                 roofline["traffic_note"] = "HBM-side fetch bytes per launch from profiles/r2_%s_mem2.json (same library build), x2 gfx950 correction" % args.config
         except (OSError, KeyError, IndexError, ValueError, ZeroDivisionError):
             pass
-        import ctypes
         sz = (ctypes.c_uint64 * 4)()
         rta.lib.rt_debug_scene_sizes(r._h, sz)  # device bytes with every derived array; record counts
         sizes = [int(x) for x in sz]

@@ -21,7 +21,7 @@
 
 using namespace rtd;
 
-#define RT_COUNTER_WORDS 28 /* rt_counters (8 words) + 20 diagnostic words of rt_device.hip.h */
+#define RT_COUNTER_WORDS 30 /* rt_counters (8 words) + 22 diagnostic words of rt_device.hip.h */
 #define RT_BLOCK 64 /* one workgroup = one wave: the LDS pool of rt_device.hip.h is per wave */
 #ifndef RT_WAVES_PER_SIMD
 #define RT_WAVES_PER_SIMD 2 /* resident waves per SIMD the render kernel is compiled for (register budget 512 / this) */
@@ -1259,12 +1259,12 @@ int rt_get_counters(rt_ctx *c, rt_counters *out) {
     return RT_OK;
 }
 
-/* not part of the public header: 20 diagnostic words of the counted kernel variant (cycle stamps per
- * phase, pool occupancy, 8 free slots for experiments), for tools/ only */
-int rt_debug_stats(rt_ctx *c, uint64_t *out20) {
-    if (!c || !out20) return RT_E_INVALID;
+/* not part of the public header: 22 diagnostic words of the counted kernel variant (cycle stamps per
+ * phase, pool occupancy, 8 free slots for experiments, exact sphere tests, sphere-tree nodes visited), for tools/ and bench.py's report only */
+int rt_debug_stats(rt_ctx *c, uint64_t *out22) {
+    if (!c || !out22) return RT_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(out20, reinterpret_cast<uint64_t *>(c->d_counters) + 8, 20 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out22, reinterpret_cast<uint64_t *>(c->d_counters) + 8, 22 * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }

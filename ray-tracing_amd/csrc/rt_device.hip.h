@@ -213,6 +213,7 @@ struct Cnt {
     uint64_t cyc_fresh, cyc_roots, cyc_node, cyc_leaf, cyc_finish, cyc_shade;
     uint64_t node_steps, node_lanes, leaf_steps, leaf_lanes, queries, query_lanes;
     uint64_t dbg[8];
+    uint64_t sph_tests, sph_nodes; /* exact sphere tests done and sphere-tree nodes visited (per lane, like the public counters) */
 };
 #define RT_STAMP() ((uint64_t)__builtin_amdgcn_s_memtime())
 #ifndef RT_STAMP_STEPS
@@ -366,6 +367,7 @@ struct HitRec {
     int32_t group; /* the triangle's texture group, for a path segment's mesh hit: read while the hit is settled, which also
                       brings the triangle's attribute record into the cache before the surface is evaluated */
     double beta, gamma;
+    int32_t sph_tests, sph_nodes; /* work done on the spheres for this ray; read only by the counted kernel variant */
 };
 
 /* ---- per-wave LDS ------------------------------------------------------------------------- */
@@ -491,6 +493,11 @@ __device__ __forceinline__ void sphere_test(SP sph, int s, V3 C, V3 u, HitRec &h
     double t = (t1 > 0) ? t1 : t2;
     if (t < h.t || (t == h.t && oid < h.obj)) { h.t = t; h.obj = oid; h.prim = s; h.mesh = -1; }
 }
+template <typename SP>
+__device__ __forceinline__ void sphere_test_counted(SP sph, int s, V3 C, V3 u, HitRec &h) {
+    h.sph_tests++;
+    sphere_test(sph, s, C, u, h);
+}
 
 __device__ __forceinline__ void hit_none(HitRec &h) {
     h.t = 1E10;
@@ -499,6 +506,7 @@ __device__ __forceinline__ void hit_none(HitRec &h) {
     h.mesh = -1;
     h.group = 0;
     h.beta = h.gamma = 0;
+    h.sph_tests = h.sph_nodes = 0;
 }
 /* the margins of the sphere tree's boxes hold for rays that start within DScene::sph_reach of the coordinate origin */
 __device__ __forceinline__ bool sphere_walk_ok(const DScene &sc, V3 C) { return fabs(C.x) < sc.sph_reach && fabs(C.y) < sc.sph_reach && fabs(C.z) < sc.sph_reach; }
@@ -521,10 +529,11 @@ template <typename SP>
 __device__ __forceinline__ void sphere_walk_step(SP sph, const RayQ &q, const SphNode &nd, SphereWalk &sw, HitRec &h) {
     bool hit, unsure;
     float tlo;
+    h.sph_nodes++;
     box_fast_f(nd.box[0], nd.box[1], nd.box[2], nd.box[3], nd.box[4], nd.box[5], sw.kf, hit, unsure, tlo);
     const double bound = h.t < q.tmax ? h.t : q.tmax;
     if (!(hit || unsure) || (double)tlo > bound) { sw.i = nd.skip; return; } /* certainly missed, or wholly behind what is known */
-    for (int s = nd.first; s < nd.first + nd.count; s++) sphere_test(sph, s, q.C, q.u, h);
+    for (int s = nd.first; s < nd.first + nd.count; s++) sphere_test_counted(sph, s, q.C, q.u, h);
     sw.i++;
 }
 
@@ -543,8 +552,8 @@ __device__ __forceinline__ void spheres_walk2(const DScene &sc, SP sph, const Ra
     if (__ballot(done_a || done_b) == 0ull) return;
     const int n_big = uni(sc.n_sph_big), n_nodes = uni(sc.n_sph_nodes);
     for (int s = 0; s < n_big; s++) {
-        if (done_a) sphere_test(sph, s, qa.C, qa.u, ha);
-        if (done_b) sphere_test(sph, s, qb.C, qb.u, hb);
+        if (done_a) sphere_test_counted(sph, s, qa.C, qa.u, ha);
+        if (done_b) sphere_test_counted(sph, s, qb.C, qb.u, hb);
     }
     SphereWalk wa, wb;
     sphere_walk_begin(sc, qa, done_a, wa);
@@ -571,7 +580,7 @@ __device__ __forceinline__ void ray_begin(const DScene &sc, WaveLDS *w, SP sph, 
     } else if (SPH && sc.sph_nodes != nullptr && prune && sphere_walk_ok(sc, C)) {
         /* a single ray's walk (the probes; the render loop walks both rays of a lane together: spheres_walk2) */
         const int n_big = uni(sc.n_sph_big), n_nodes = uni(sc.n_sph_nodes);
-        for (int s = 0; s < n_big; s++) sphere_test(sph, s, C, u, h);
+        for (int s = 0; s < n_big; s++) sphere_test_counted(sph, s, C, u, h);
         SphereWalk sw;
         sphere_walk_begin(sc, q, true, sw);
         for (int guard = 0; sw.i < n_nodes && guard <= n_nodes; guard++) {
@@ -579,8 +588,9 @@ __device__ __forceinline__ void ray_begin(const DScene &sc, WaveLDS *w, SP sph, 
             sphere_walk_step(sph, q, nd, sw, h);
         }
     } else {
-        for (int s = 0; s < n_sph; s++) sphere_test(sph, s, C, u, h);
+        for (int s = 0; s < n_sph; s++) sphere_test_counted(sph, s, C, u, h);
     }
+    if (CNT) { cnt.sph_tests += (uint64_t)h.sph_tests; cnt.sph_nodes += (uint64_t)h.sph_nodes; }
     if (sc.n_meshes == 0) return;
     /* Mesh hits are accepted only below t0 = min(1E9, sphere hit, tmax): TriangleMesh::intersect starts at
      * t = 1E9 (raytracer.cpp:647), a mesh hit beyond the closest sphere loses in Scene::intersect (:938)
@@ -1510,6 +1520,13 @@ __device__ __forceinline__ void flush_counters(const Cnt &c, rt_counters *out) {
     if ((threadIdx.x & 63) == 0) {
         for (int q = 0; q < 12; q++) atomicAdd(o + 8 + q, (unsigned long long)d[q]);
         for (int q = 0; q < 8; q++) atomicAdd(o + 20 + q, (unsigned long long)c.dbg[q]);
+    }
+    uint64_t e[2] = {c.sph_tests, c.sph_nodes};
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        uint64_t x = e[q];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor((unsigned long long)x, off, 64);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd(o + 28 + q, (unsigned long long)x);
     }
 }
 
