@@ -687,14 +687,14 @@ __device__ __forceinline__ void rays_end(const DScene &sc, WaveLDS *w, int lane,
 
 /* the mesh root box of one ray (raytracer.cpp:644); k and thr are the ray's constants as read at the start of the feed */
 template <bool CNT>
-__device__ __forceinline__ bool root_test(const DScene &sc, const RootRec &m, int mesh, const RayQ &q, const RayKf &k, float thr, float &fn, Cnt &cnt) {
-    if (!q.active) return false;
+__device__ __forceinline__ bool root_test(const DScene &sc, const WaveLDS *w, const RootRec &m, int mesh, bool active, int slot, const RayKf &k, float thr, float &fn, Cnt &cnt) {
+    if (!active) return false;
     if (CNT) cnt.box_tests++;
     bool pass, unsure;
     float tn;
     box_fast_f(m.box[0], m.box[1], m.box[2], m.box[3], m.box[4], m.box[5], k, pass, unsure, tn);
-    if (__builtin_expect(unsure, 0)) {
-        pass = box_hit_exact(sc.meshes[mesh].root_box, q.C.x, q.C.y, q.C.z, q.u.x, q.u.y, q.u.z);
+    if (__builtin_expect(unsure, 0)) { /* the ray as ray_begin stored it */
+        pass = box_hit_exact(sc.meshes[mesh].root_box, w->ray[0][slot], w->ray[1][slot], w->ray[2][slot], w->ray[3][slot], w->ray[4][slot], w->ray[5][slot]);
         tn = -__builtin_huge_valf();
     }
     if (CNT && pass) cnt.mesh_calls++;
@@ -771,34 +771,14 @@ __device__ __forceinline__ void wide_children(const DScene &sc, WaveLDS *w, int 
     }
 }
 
-/* Scene::intersect, raytracer.cpp:930-951, for up to two rays per lane (slots lane and 64 + lane). Called by all
- * 64 lanes together; active rays get their closest hit. */
-/* SPH: compiled with the walk through the sphere tree (scenes with long sphere lists); without it the code for short
- * lists is exactly what it was before the tree existed. */
-template <bool CNT, bool SPH, typename SP>
-__device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScene &cold, WaveLDS *w, SP sph, const RootRec *roots, const RayQ &qa0, const RayQ &qb0,
-                                                   bool prune, HitRec &ha, HitRec &hb, Cnt &cnt) {
+/* The pool traversal of one query: everything between "the rays' tables are in LDS" (ray_begin) and "the rays' best
+ * triangles are in LDS" (rays_end). It takes nothing per lane but the two activity masks and leaves nothing per lane
+ * behind: all of its inputs and outputs are the wave's LDS tables. */
+template <bool CNT>
+__device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &cold, WaveLDS *w, const RootRec *roots, bool own, bool prune,
+                                              unsigned long long mask_a, unsigned long long mask_b, Cnt &cnt, uint64_t &st0) {
     const int lane = lane_id();
-    uint64_t st0 = 0;
-    if (CNT) { st0 = RT_STAMP(); cnt.queries++; cnt.query_lanes += (uint64_t)(__popcll(__ballot(qa0.active)) + __popcll(__ballot(qb0.active))); }
-    RayQ qa = qa0, qb = qb0;
-    /* First on the filter tree (one tree over all meshes; not for the counted variant or RT_F_NO_PRUNE, which
-     * reproduce the reference's traversal); the rays whose winner could not be confirmed go round again on the
-     * reference's trees. */
-#ifdef RT_DIAG_OWN /* diagnostic build: the counted variant also runs on the filter tree (its counters then differ from the reference's) */
-    bool own = prune && sc.own_rec4 != nullptr;
-#else
-    bool own = !CNT && prune && sc.own_rec4 != nullptr;
-#endif
-    HitRec kept_a = {}, kept_b = {};
-    bool kept = false, redo_a = false, redo_b = false;
-  for (;;) {
-    bool sa = false, sb = false;
-    if (SPH && cold.sph_nodes != nullptr && prune) spheres_walk2(cold, sph, qa, qb, ha, hb, sa, sb);
-    ray_begin<CNT, SPH>(cold, w, sph, lane, qa, prune, sa, ha, cnt);
-    ray_begin<CNT, SPH>(cold, w, sph, RT_WAVE + lane, qb, prune, sb, hb, cnt);
-    if (CNT) { const uint64_t t = RT_STAMP(); cnt.cyc_roots += t - st0; st0 = t; } /* spheres and ray constants count with the roots */
-    if (sc.n_meshes == 0) return;
+    const bool act_a = (mask_a >> lane) & 1ull, act_b = (mask_b >> lane) & 1ull;
     const NodeRec32 *const recs = sc.rec32;
     const rt_tri *const tri_base = own ? sc.own_tris : sc.tris;
     const uint32_t n_recs = own ? sc.n_own_nodes : sc.n_nodes_total;
@@ -823,13 +803,13 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScen
             const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3], q4 = rp[4], q5 = rp[5];
             const uint4 ch = *reinterpret_cast<const uint4 *>(rp + 6);
             const float ninf = -__builtin_huge_valf();
-            wide_children(sc, w, lane, qa.active, lane, ninf, q0, q1, q2, q3, q4, q5, ch, n_nodes, n_leaves);
-            const unsigned long long bb = __ballot(qb.active);
+            wide_children(sc, w, lane, act_a, lane, ninf, q0, q1, q2, q3, q4, q5, ch, n_nodes, n_leaves);
+            const unsigned long long bb = __ballot(act_b);
             const int nb = __popcll(bb);
             if (n_nodes + 4 * nb <= node_soft && n_leaves + 4 * nb <= RT_LEAF_CAP) {
-                wide_children(sc, w, lane, qb.active, RT_WAVE + lane, ninf, q0, q1, q2, q3, q4, q5, ch, n_nodes, n_leaves);
+                wide_children(sc, w, lane, act_b, RT_WAVE + lane, ninf, q0, q1, q2, q3, q4, q5, ch, n_nodes, n_leaves);
             } else {
-                if (qb.active) w->node[n_nodes + rank_in(bb)] = make_uint2((uint32_t)(RT_WAVE + lane) << RT_NODE_BITS, __float_as_uint(ninf));
+                if (act_b) w->node[n_nodes + rank_in(bb)] = make_uint2((uint32_t)(RT_WAVE + lane) << RT_NODE_BITS, __float_as_uint(ninf));
                 n_nodes += nb;
             }
             wave_sync();
@@ -840,8 +820,8 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScen
             do {
                 const RootRec &m = roots[mi];
                 float fa = 0.f, fb = 0.f;
-                const bool pa = root_test<CNT>(cold, m, mi, qa, ka, thr_a, fa, cnt);
-                const bool pb = root_test<CNT>(cold, m, mi, qb, kb, thr_b, fb, cnt);
+                const bool pa = root_test<CNT>(cold, w, m, mi, act_a, lane, ka, thr_a, fa, cnt);
+                const bool pb = root_test<CNT>(cold, w, m, mi, act_b, RT_WAVE + lane, kb, thr_b, fb, cnt);
                 mi++;
                 const unsigned long long ba = __ballot(pa), bb = __ballot(pb);
                 if ((ba | bb) == 0ull) continue;
@@ -1074,6 +1054,42 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScen
                 if (CNT) { uint64_t t = RT_STAMP(); cnt.cyc_node += t - st0; st0 = t; cnt.node_steps++; cnt.node_lanes += (uint64_t)k; }
             }
         }
+    }
+}
+
+/* Scene::intersect, raytracer.cpp:930-951, for up to two rays per lane (slots lane and 64 + lane). Called by all
+ * 64 lanes together; active rays get their closest hit. */
+/* SPH: compiled with the walk through the sphere tree (scenes with long sphere lists); without it the code for short
+ * lists is exactly what it was before the tree existed. */
+template <bool CNT, bool SPH, typename SP>
+__device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScene &cold, WaveLDS *w, SP sph, const RootRec *roots, const RayQ &qa0, const RayQ &qb0,
+                                                   bool prune, HitRec &ha, HitRec &hb, Cnt &cnt) {
+    const int lane = lane_id();
+    uint64_t st0 = 0;
+    if (CNT) { st0 = RT_STAMP(); cnt.queries++; cnt.query_lanes += (uint64_t)(__popcll(__ballot(qa0.active)) + __popcll(__ballot(qb0.active))); }
+    RayQ qa = qa0, qb = qb0;
+    /* First on the filter tree (one tree over all meshes; not for the counted variant or RT_F_NO_PRUNE, which
+     * reproduce the reference's traversal); the rays whose winner could not be confirmed go round again on the
+     * reference's trees. */
+#ifdef RT_DIAG_OWN /* diagnostic build: the counted variant also runs on the filter tree (its counters then differ from the reference's) */
+    bool own = prune && sc.own_rec4 != nullptr;
+#else
+    bool own = !CNT && prune && sc.own_rec4 != nullptr;
+#endif
+    HitRec kept_a = {}, kept_b = {};
+    bool kept = false, redo_a = false, redo_b = false;
+  for (;;) {
+    bool sa = false, sb = false;
+    if (SPH && cold.sph_nodes != nullptr && prune) spheres_walk2(cold, sph, qa, qb, ha, hb, sa, sb);
+    ray_begin<CNT, SPH>(cold, w, sph, lane, qa, prune, sa, ha, cnt);
+    ray_begin<CNT, SPH>(cold, w, sph, RT_WAVE + lane, qb, prune, sb, hb, cnt);
+    if (CNT) { const uint64_t t = RT_STAMP(); cnt.cyc_roots += t - st0; st0 = t; } /* spheres and ray constants count with the roots */
+    if (sc.n_meshes == 0) return;
+    {
+        const unsigned long long mask_a = wave_ballot(qa.active), mask_b = wave_ballot(qb.active);
+        /* inlined on purpose: as a real call (scene fields from the LDS copy, the path state saved around it) the kernel
+         * ran 9 % slower at the same occupancy, and compiled for three waves per SIMD 24 % slower */
+        pool_traverse<CNT>(sc, cold, w, roots, own, prune, mask_a, mask_b, cnt, st0);
     }
     bool da, db;
     rays_end(cold, w, lane, qa, qb, own, ha, hb, da, db);
