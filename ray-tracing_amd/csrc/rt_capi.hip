@@ -447,20 +447,14 @@ static int32_t ext_split(const rt_tri *tris, int32_t first, int32_t n, std::vect
     return best;
 }
 
-#ifndef RT_SPHERE_LEAF
-#define RT_SPHERE_LEAF 1 /* spheres per leaf of the sphere tree. Measured on 1006 spheres (Mpaths/s): 1: 86, 2: 80, 4: 70, 8: 58, 16: 45 -
-                            the exact FP64 tests cost more than the extra nodes of a deeper tree */
-#endif
-/* The tree over a long sphere list (SphNode in rt_device.hip.h): median cuts of the centres along the widest axis down to
- * leaves of RT_SPHERE_LEAF spheres, nodes in depth-first order with skip links - eight such orders, one per sign pattern
- * of a ray's direction, concatenated -, spheres re-ordered into leaf order. `reach` is how
- * far from the coordinate origin a ray may start for the margin of the boxes to hold: a hundred thousand times the
+/* The tree over a long sphere list: the filter tree's builder (rt_own_bvh.hpp: binned surface-area cuts, four children per
+ * record, leaves of at most four spheres) over the spheres' boxes; the spheres are re-ordered into its leaf order. `reach`
+ * is how far from the coordinate origin a ray may start for the margin of the boxes to hold: a hundred thousand times the
  * smallest radius, less the largest centre coordinate. (Sphere::intersect accepts delta = b^2 - 4c >= 0 as computed; its
  * rounding error is below 64 * 2^-53 |C - O|^2, so an accepted ray passes the centre within R sqrt(1 + 16 * 2^-53 |C - O|^2 / R^2)
  * <= R (1 + 3e-5) when |C - O| <= sqrt(3) * 1e5 R: inside the boxes' margin of R / 1000.) Returns false for a non-finite sphere. */
-static bool build_sphere_tree(const rt_sphere *sph, int n_all, std::vector<rt_sphere> &sorted, std::vector<SphNode> &nodes, std::vector<double> &boxes_out,
-                              double *reach, int *n_big_out) {
-    const int n = n_all;
+static bool build_sphere_tree(const rt_sphere *sph, int n, std::vector<rt_sphere> &sorted, rtown::Built &tree, std::vector<double> &boxes_out, double *reach,
+                              int *n_big_out) {
     std::vector<int> idx((size_t)n);
     double rmin = HUGE_VAL, omax = 0;
     for (int i = 0; i < n; i++) {
@@ -473,13 +467,9 @@ static bool build_sphere_tree(const rt_sphere *sph, int n_all, std::vector<rt_sp
         if (sph[i].R < rmin) rmin = sph[i].R;
     }
     *reach = 1e5 * rmin - omax; /* <= 0: every ray tests every sphere */
-    auto sphere_box = [&](int i, double *b) {
-        const double m = sph[i].R * 1.001 + 1e-300;
-        for (int a = 0; a < 3; a++) { b[a] = sph[i].O[a] - m; b[3 + a] = sph[i].O[a] + m; }
-    };
     /* Spheres much larger than the rest (the walls of the reference's scenes are spheres of radius ~1000) would blow up
      * every box above them: they stay out of the tree, at the front of the list, and every ray tests them first - which
-     * also gives the walk a closest hit to prune with. */
+     * also gives the traversal a closest hit to prune with. */
     int n_big = 0;
     {
         std::vector<double> radii((size_t)n);
@@ -490,103 +480,20 @@ static bool build_sphere_tree(const rt_sphere *sph, int n_all, std::vector<rt_sp
         if (n_big > RT_LDS_SPHERES_MAX || n_big == n) n_big = 0; /* no such outliers (or only such): everything goes into the tree */
     }
     *n_big_out = n_big;
-    /* the tree itself: median cuts, children by index */
-    struct BNode { float box[6]; int left, right, axis, first, count; };
-    std::vector<BNode> tree;
-    {
-        struct Job { int node, first, count; };
-        std::vector<Job> jobs;
-        tree.push_back(BNode{});
-        jobs.push_back(Job{0, n_big, n - n_big});
-        while (!jobs.empty()) {
-            const Job jb = jobs.back();
-            jobs.pop_back();
-            double box[6] = {HUGE_VAL, HUGE_VAL, HUGE_VAL, -HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
-            double clo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, chi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
-            for (int k = jb.first; k < jb.first + jb.count; k++) {
-                double b[6];
-                sphere_box(idx[(size_t)k], b);
-                for (int a = 0; a < 3; a++) {
-                    if (b[a] < box[a]) box[a] = b[a];
-                    if (b[3 + a] > box[3 + a]) box[3 + a] = b[3 + a];
-                    const double ctr = sph[idx[(size_t)k]].O[a];
-                    if (ctr < clo[a]) clo[a] = ctr;
-                    if (ctr > chi[a]) chi[a] = ctr;
-                }
-            }
-            BNode nd;
-            memset(&nd, 0, sizeof nd);
-            for (int a = 0; a < 3; a++) {
-                nd.box[a] = nextafterf((float)box[a], -HUGE_VALF);
-                nd.box[3 + a] = nextafterf((float)box[3 + a], HUGE_VALF);
-            }
-            for (int a = 0; a < 6; a++) boxes_out.push_back((double)nd.box[a]);
-            nd.left = nd.right = -1;
-            nd.first = jb.first;
-            nd.count = jb.count;
-            if (jb.count > RT_SPHERE_LEAF) {
-                int axis = 0;
-                for (int a = 1; a < 3; a++)
-                    if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
-                const int half = jb.count / 2;
-                std::nth_element(idx.begin() + jb.first, idx.begin() + jb.first + half, idx.begin() + jb.first + jb.count,
-                                 [&](int x, int y) { return sph[x].O[axis] < sph[y].O[axis] || (sph[x].O[axis] == sph[y].O[axis] && x < y); });
-                nd.axis = axis;
-                nd.left = (int)tree.size();
-                nd.right = nd.left + 1;
-                tree.push_back(BNode{});
-                tree.push_back(BNode{});
-                jobs.push_back(Job{nd.left, jb.first, half});               /* lower centres */
-                jobs.push_back(Job{nd.right, jb.first + half, jb.count - half}); /* upper centres */
-            }
-            tree[(size_t)jb.node] = nd;
-        }
+    std::vector<rtown::Bounds> tb((size_t)(n - n_big));
+    for (int k = n_big; k < n; k++) {
+        const rt_sphere &sp = sph[idx[(size_t)k]];
+        const double m = sp.R * 1.001 + 1e-300;
+        rtown::Bounds &b = tb[(size_t)(k - n_big)];
+        for (int a = 0; a < 3; a++) { b.lo[a] = sp.O[a] - m; b.hi[a] = sp.O[a] + m; }
+        for (int a = 0; a < 3; a++) { boxes_out.push_back(b.lo[a]); }
+        for (int a = 0; a < 3; a++) { boxes_out.push_back(b.hi[a]); }
     }
-    /* Eight depth-first layouts, one per sign pattern of a ray's direction: in layout o the child that a ray of that
-     * pattern reaches first (the lower one along the cut's axis if the ray runs up that axis) comes first, so the walk
-     * meets near spheres before far ones and the closest hit so far cuts off what lies behind it. */
-    const int per = (int)tree.size();
-    nodes.assign((size_t)per * 8, SphNode{});
-    for (int o = 0; o < 8; o++) {
-        struct Frame { int bnode, out, stage; };
-        std::vector<Frame> st;
-        int emitted = 0;
-        st.push_back(Frame{0, -1, 0});
-        while (!st.empty()) {
-            Frame &f = st.back();
-            const BNode &bn = tree[(size_t)f.bnode];
-            if (f.stage == 0) {
-                f.out = emitted++;
-                SphNode &nd = nodes[(size_t)o * per + f.out];
-                for (int a = 0; a < 6; a++) nd.box[a] = bn.box[a];
-                if (bn.left < 0) {
-                    nd.first = bn.first;
-                    nd.count = bn.count;
-                    nd.skip = f.out + 1;
-                    st.pop_back();
-                    continue;
-                }
-                nd.first = 0;
-                nd.count = 0;
-                f.stage = 1;
-                const bool down = (o >> bn.axis) & 1; /* the ray runs down the axis: upper child first */
-                const Frame nxt{down ? bn.right : bn.left, -1, 0};
-                st.push_back(nxt); /* invalidates f */
-                continue;
-            }
-            if (f.stage == 1) {
-                f.stage = 2;
-                const bool down = (o >> bn.axis) & 1;
-                const Frame nxt{down ? bn.left : bn.right, -1, 0};
-                st.push_back(nxt);
-                continue;
-            }
-            nodes[(size_t)o * per + f.out].skip = emitted; /* the node after this subtree */
-            st.pop_back();
-        }
-    }
+    tree = rtown::build_boxes(tb);
+    if (!tree.ok) return false;
     sorted.resize((size_t)n);
-    for (int i = 0; i < n; i++) sorted[(size_t)i] = sph[idx[(size_t)i]];
+    for (int i = 0; i < n_big; i++) sorted[(size_t)i] = sph[idx[(size_t)i]];
+    for (int k = 0; k < n - n_big; k++) sorted[(size_t)(n_big + k)] = sph[idx[(size_t)(n_big + tree.order[(size_t)k])]];
     return true;
 }
 
@@ -686,22 +593,26 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
     free_scene(c);
     DScene d{};
     int rc;
-    int ext_depth = 0, own_depth = 0;
+    int ext_depth = 0, own_depth = 0, sph_depth = 0;
     std::vector<int32_t> ext_root((size_t)s->n_meshes, -1); /* extension record that replaces a mesh's root leaf */
     std::vector<double> sphere_boxes; /* of the sphere tree: they count for the box tests' tolerance like every other box */
     if (s->n_spheres > RT_LDS_SPHERES_MAX) {
-        /* Long sphere lists: a tree over the spheres' boxes (rt_device.hip.h: SphNode); the spheres go up in its leaf order. */
+        /* Long sphere lists: a tree over the spheres' boxes in the filter tree's format; the spheres go up in its leaf order. */
         std::vector<rt_sphere> sorted;
-        std::vector<SphNode> nodes;
+        rtown::Built tree;
         double reach = 0;
         int n_big = 0;
-        if (!build_sphere_tree(s->spheres, s->n_spheres, sorted, nodes, sphere_boxes, &reach, &n_big))
+        if (!build_sphere_tree(s->spheres, s->n_spheres, sorted, tree, sphere_boxes, &reach, &n_big))
             return fail(c, RT_E_INVALID, "rt_upload_scene: a sphere has a non-finite centre or radius");
+        std::vector<int32_t> of_obj((size_t)n_obj, -1);
+        for (size_t k = 0; k < sorted.size(); k++) of_obj[(size_t)sorted[k].object_id] = (int32_t)k;
         if ((rc = upload_array(c, sorted.data(), sorted.size(), &d.spheres))) return rc;
-        if ((rc = upload_array(c, nodes.data(), nodes.size(), &d.sph_nodes))) return rc;
-        d.n_sph_nodes = (int32_t)(nodes.size() / 8); /* per layout */
+        if ((rc = upload_array(c, tree.wide.data(), tree.wide.size(), &d.sph_rec4))) return rc;
+        if ((rc = upload_array(c, of_obj.data(), of_obj.size(), &d.sph_of_obj))) return rc;
+        d.n_sph_rec4 = (uint32_t)tree.wide.size();
         d.sph_reach = reach;
         d.n_sph_big = n_big;
+        sph_depth = 3 * tree.wide_depth + 2; /* stack entries the depth-first tail of the traversal can add */
         for (size_t k = 0; k + 6 <= sphere_boxes.size(); k += 6) widen(&sphere_boxes[k]);
         HIPCHK(c, hipStreamSynchronize(c->stream)); /* the staging vectors go out of scope */
     } else if ((rc = upload_array(c, s->spheres, (size_t)s->n_spheres, &d.spheres))) {
@@ -890,7 +801,7 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
         d.lightR = light->R;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream)); /* host arrays may be released after return */
-    const int depth_need = (own_depth > max_depth + ext_depth ? own_depth : max_depth + ext_depth) + 2;
+    const int depth_need = std::max(std::max(own_depth, sph_depth), max_depth + ext_depth) + 2;
     const size_t lds_fixed = sizeof(WaveLDS) + 16 + ((s->n_spheres <= RT_LDS_SPHERES_MAX) ? (size_t)s->n_spheres * sizeof(rt_sphere) : 0);
     {
         /* One more resident wave per CU is worth more than a tall stack (measured: +11 % for the eighth wave, -2 % for
@@ -1037,9 +948,9 @@ static int render_impl(rt_ctx *c, const rt_camera *cam, const rt_params *p, doub
         const int64_t tiles_all = tiles * (chunk < nk ? n_units : 1); /* 64-slot requests that the launch hands out */
         const unsigned pgrid = (unsigned)(tiles_all < resident ? tiles_all : resident);
         HIPCHK(c, hipMemsetAsync(next_slot, 0, sizeof(int), c->stream));
-        if (c->sc.sph_nodes != nullptr && (p->flags & RT_F_COUNTERS))
+        if (c->sc.sph_rec4 != nullptr && (p->flags & RT_F_COUNTERS))
             hipLaunchKernelGGL(rt_render_spheres_kernel<true>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, unit_sums, c->d_counters, next_slot, n_slots);
-        else if (c->sc.sph_nodes != nullptr)
+        else if (c->sc.sph_rec4 != nullptr)
             hipLaunchKernelGGL(rt_render_spheres_kernel<false>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, unit_sums, c->d_counters, next_slot, n_slots);
         else if (p->flags == 0)
             hipLaunchKernelGGL((rt_render_kernel<false, true>), dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, unit_sums, c->d_counters, next_slot, n_slots);

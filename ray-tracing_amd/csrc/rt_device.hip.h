@@ -79,17 +79,6 @@ static_assert(RT_NODE_SOFT_MIN > RT_FEED_MARGIN + RT_WAVE && RT_NODE_SOFT_MIN <=
 static_assert(RT_LEAF_CAP >= 5 * RT_WAVE, "a node step adds up to 256 leaf items (filter tree: four children) and runs only when 256 slots are free; a fed mesh adds up to 128 on top of 64");
 #define RT_PHANTOM_BASE (1 << 30)  /* best_pos values from here on: "mesh (value - base) reports a hit without a triangle" */
 
-/* One node of the sphere tree, 48 bytes. Nodes lie in depth-first order (eight orders, one per sign pattern of the ray's
- * direction, n_sph_nodes each): a ray that may touch `box` goes on with the next node, any other with node `skip`; a leaf (count > 0) holds spheres first .. first + count - 1 and its skip is the next
- * node. The boxes are the spheres' boxes enlarged by a thousandth of the radius and rounded outwards to float: Sphere::
- * intersect (raytracer.cpp:883-918) can report a hit for a ray that passes a sphere by a rounding error, which stays
- * inside that margin as long as the ray starts within a hundred thousand radii (DScene::sph_reach). */
-struct SphNode {
-    float box[6];
-    int32_t skip, first, count;
-    int32_t pad[3];
-};
-
 /* what the root phase needs of a mesh: the root box (raytracer.cpp:644) and where the tree starts */
 struct RootRec { /* 32 bytes; the box rounded to float like NodeRec32, the double box stays in rt_mesh */
     float box[6];
@@ -149,10 +138,15 @@ struct DScene {
     uint32_t n_tris_total, n_nodes_total; /* array lengths: every index taken from the pool is checked against them */
     uint32_t n_ref_nodes;                 /* records below this index are the reference's; the rest are extension records */
     int *overflow;    /* bit 0: a push would have passed a stack's capacity; bit 1: an index outside the arrays */
-    /* Sphere lists too long for LDS: a tree over the spheres' boxes (SphNode, depth-first order with skip links) that a lane
-     * walks without a stack; `spheres` is then in the tree's leaf order. Null for short lists. */
-    const struct SphNode *sph_nodes;
-    int32_t n_sph_nodes; /* per direction layout */
+    /* Sphere lists too long for LDS: a tree over the spheres' boxes, in the filter tree's record format (four children per
+     * record), that the wave's pool traverses like the triangles' tree; `spheres` is then in that tree's leaf order behind
+     * the n_sph_big spheres that are not in it. Null for short lists. The boxes are the spheres' boxes enlarged by a
+     * thousandth of the radius and rounded outwards to float: Sphere::intersect (raytracer.cpp:883-918) can report a hit
+     * for a ray that passes a sphere by a rounding error, which stays inside that margin as long as the ray starts within
+     * a hundred thousand radii (sph_reach). */
+    const NodeRec4 *sph_rec4;
+    const int32_t *sph_of_obj; /* by objectId: position of that sphere in `spheres` (-1 for a mesh) */
+    uint32_t n_sph_rec4;
     int32_t n_sph_big;   /* spheres at the front of the list that are not in the tree (far larger than the rest): tested by every ray */
     double sph_reach; /* rays whose origin lies farther than this from the coordinate origin (any axis) test every sphere instead */
     double I;
@@ -511,61 +505,6 @@ __device__ __forceinline__ void hit_none(HitRec &h) {
 /* the margins of the sphere tree's boxes hold for rays that start within DScene::sph_reach of the coordinate origin */
 __device__ __forceinline__ bool sphere_walk_ok(const DScene &sc, V3 C) { return fabs(C.x) < sc.sph_reach && fabs(C.y) < sc.sph_reach && fabs(C.z) < sc.sph_reach; }
 
-struct SphereWalk { /* one ray's walk through the sphere tree */
-    RayKf kf;
-    const SphNode *layout;
-    int i;
-};
-__device__ __forceinline__ void sphere_walk_begin(const DScene &sc, const RayQ &q, bool on, SphereWalk &sw) {
-    const RayK k = ray_constants(sc, q.C, q.u);
-    sw.kf.iux = (float)k.iu.x; sw.kf.iuy = (float)k.iu.y; sw.kf.iuz = (float)k.iu.z;
-    sw.kf.ncx = (float)k.nc.x; sw.kf.ncy = (float)k.nc.y; sw.kf.ncz = (float)k.nc.z;
-    sw.kf.tol = (float)(k.tol * RT_TOLF_SCALE);
-    /* the layout for this ray's direction: near children first */
-    sw.layout = sc.sph_nodes + (size_t)((q.u.x < 0 ? 1 : 0) | (q.u.y < 0 ? 2 : 0) | (q.u.z < 0 ? 4 : 0)) * (size_t)sc.n_sph_nodes;
-    sw.i = on ? 0 : sc.n_sph_nodes;
-}
-template <typename SP>
-__device__ __forceinline__ void sphere_walk_step(SP sph, const RayQ &q, const SphNode &nd, SphereWalk &sw, HitRec &h) {
-    bool hit, unsure;
-    float tlo;
-    h.sph_nodes++;
-    box_fast_f(nd.box[0], nd.box[1], nd.box[2], nd.box[3], nd.box[4], nd.box[5], sw.kf, hit, unsure, tlo);
-    const double bound = h.t < q.tmax ? h.t : q.tmax;
-    if (!(hit || unsure) || (double)tlo > bound) { sw.i = nd.skip; return; } /* certainly missed, or wholly behind what is known */
-    for (int s = nd.first; s < nd.first + nd.count; s++) sphere_test_counted(sph, s, q.C, q.u, h);
-    sw.i++;
-}
-
-/* Long sphere lists, both rays of a lane at once (their walks are chains of dependent loads: two chains in flight
- * take the time of the longer one). Only the spheres whose (enlarged) boxes a ray may touch, and that can still
- * matter - nearer than the closest hit so far and than tmax -, get the exact test; the winner is the same, because
- * the choice among tested spheres (smallest t, then smallest objectId) does not depend on their order. Rays outside
- * the tree's reach are left to ray_begin (done_* stays false). */
-template <typename SP>
-__device__ __forceinline__ void spheres_walk2(const DScene &sc, SP sph, const RayQ &qa, const RayQ &qb, HitRec &ha, HitRec &hb, bool &done_a,
-                                              bool &done_b) {
-    hit_none(ha);
-    hit_none(hb);
-    done_a = qa.active && sphere_walk_ok(sc, qa.C);
-    done_b = qb.active && sphere_walk_ok(sc, qb.C);
-    if (__ballot(done_a || done_b) == 0ull) return;
-    const int n_big = uni(sc.n_sph_big), n_nodes = uni(sc.n_sph_nodes);
-    for (int s = 0; s < n_big; s++) {
-        if (done_a) sphere_test_counted(sph, s, qa.C, qa.u, ha);
-        if (done_b) sphere_test_counted(sph, s, qb.C, qb.u, hb);
-    }
-    SphereWalk wa, wb;
-    sphere_walk_begin(sc, qa, done_a, wa);
-    sphere_walk_begin(sc, qb, done_b, wb);
-    for (int guard = 0; (wa.i < n_nodes || wb.i < n_nodes) && guard <= 2 * n_nodes; guard++) {
-        const bool go_a = wa.i < n_nodes, go_b = wb.i < n_nodes;
-        const SphNode na = wa.layout[go_a ? wa.i : 0], nb = wb.layout[go_b ? wb.i : 0];
-        if (go_a) sphere_walk_step(sph, qa, na, wa, ha);
-        if (go_b) sphere_walk_step(sph, qb, nb, wb, hb);
-    }
-}
-
 /* Spheres for one ray and the ray's entry in the pool's tables. */
 template <bool CNT, bool SPH, typename SP>
 __device__ __forceinline__ void ray_begin(const DScene &sc, WaveLDS *w, SP sph, int slot, const RayQ &q, bool prune, bool spheres_done,
@@ -576,17 +515,7 @@ __device__ __forceinline__ void ray_begin(const DScene &sc, WaveLDS *w, SP sph, 
     if (CNT) cnt.rays++;
     const int n_sph = uni(sc.n_spheres); /* wave-uniform also when read from LDS */
     if (spheres_done) {
-        /* spheres_walk2 has been here */
-    } else if (SPH && sc.sph_nodes != nullptr && prune && sphere_walk_ok(sc, C)) {
-        /* a single ray's walk (the probes; the render loop walks both rays of a lane together: spheres_walk2) */
-        const int n_big = uni(sc.n_sph_big), n_nodes = uni(sc.n_sph_nodes);
-        for (int s = 0; s < n_big; s++) sphere_test_counted(sph, s, C, u, h);
-        SphereWalk sw;
-        sphere_walk_begin(sc, q, true, sw);
-        for (int guard = 0; sw.i < n_nodes && guard <= n_nodes; guard++) {
-            const SphNode nd = sw.layout[sw.i];
-            sphere_walk_step(sph, q, nd, sw, h);
-        }
+        /* spheres_pool has been here */
     } else {
         for (int s = 0; s < n_sph; s++) sphere_test_counted(sph, s, C, u, h);
     }
@@ -774,15 +703,19 @@ __device__ __forceinline__ void wide_children(const DScene &sc, WaveLDS *w, int 
 /* The pool traversal of one query: everything between "the rays' tables are in LDS" (ray_begin) and "the rays' best
  * triangles are in LDS" (rays_end). It takes nothing per lane but the two activity masks and leaves nothing per lane
  * behind: all of its inputs and outputs are the wave's LDS tables. */
-template <bool CNT>
+/* SPHP: the same traversal over the tree of a long sphere list (own must be true): its leaves are ranges of spheres, the
+ * leaf step tests 64 (ray, sphere) pairs with Sphere::intersect's arithmetic, and the per-ray minimum is kept under
+ * Scene::intersect's rule for spheres (smallest t, then smallest objectId) in the same two tables. */
+template <bool CNT, bool SPHP = false>
 __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &cold, WaveLDS *w, const RootRec *roots, bool own, bool prune,
                                               unsigned long long mask_a, unsigned long long mask_b, Cnt &cnt, uint64_t &st0) {
     const int lane = lane_id();
     const bool act_a = (mask_a >> lane) & 1ull, act_b = (mask_b >> lane) & 1ull;
     const NodeRec32 *const recs = sc.rec32;
+    const NodeRec4 *const tree4 = SPHP ? sc.sph_rec4 : sc.own_rec4;
     const rt_tri *const tri_base = own ? sc.own_tris : sc.tris;
-    const uint32_t n_recs = own ? sc.n_own_nodes : sc.n_nodes_total;
-    const uint32_t n_tri_lim = own ? sc.n_own_tris : sc.n_tris_total;
+    const uint32_t n_recs = SPHP ? sc.n_sph_rec4 : (own ? sc.n_own_nodes : sc.n_nodes_total);
+    const uint32_t n_tri_lim = SPHP ? (uint32_t)(sc.n_spheres - sc.n_sph_big) : (own ? sc.n_own_tris : sc.n_tris_total);
     const int node_soft = sc.node_soft, feed_below = sc.node_soft - RT_FEED_MARGIN;
     const int n_feed = own ? 1 : sc.n_meshes;
 
@@ -799,7 +732,7 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
              * right away (the record is read with wave-uniform addresses). The second rays go the same way if their
              * pushes are sure to fit; otherwise they enter as items for record 0 and take an ordinary step. */
             mi = 1;
-            const float4 *rp = reinterpret_cast<const float4 *>(sc.own_rec4);
+            const float4 *rp = reinterpret_cast<const float4 *>(tree4);
             const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3], q4 = rp[4], q5 = rp[5];
             const uint4 ch = *reinterpret_cast<const uint4 *>(rp + 6);
             const float ninf = -__builtin_huge_valf();
@@ -903,9 +836,38 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
                 }
                 /* all coordinate loads and the ray's LDS reads are issued before anything is waited for:
                  * unconditional (a lane without a triangle reads triangle 0), fenced, then pinned */
-                Tri3 tv = tri_load(tri_base, ok ? tri : 0u);
+                Tri3 tv;
+                int32_t key = 0; /* what the per-ray minimum is broken ties with: position in the reference's order / objectId */
                 V3 rc = mk(w->ray[0][rl], w->ray[1][rl], w->ray[2][rl]);
                 V3 ru = mk(w->ray[3][rl], w->ray[4][rl], w->ray[5][rl]);
+                if (SPHP) {
+                    /* Sphere::intersect, raytracer.cpp:883-918, on sphere n_sph_big + tri of the list; a hit counts below
+                     * Scene::intersect's initial t = 1E10 (:932, strict '<' at :938) */
+                    const rt_sphere *sp = in_global(sc.spheres) + (size_t)sc.n_sph_big + (ok ? tri : 0u);
+                    const V3 O = ld3(sp->O);
+                    const double R = sp->R;
+                    key = sp->object_id;
+                    if (ok) {
+                        if (CNT) cnt.sph_tests++;
+                        const double a = 1;
+                        const V3 CO = sub(rc, O);
+                        const double b = 2 * dot(ru, CO);
+                        const double c = norm2(CO) - R * R;
+                        const double delta = b * b - 4 * a * c;
+                        if (!(delta < 0)) {
+                            const double sq = sqrt(delta);
+                            const double t2 = (-b + sq) / (2 * a);
+                            if (!(t2 < 0)) {
+                                const double t1 = (-b - sq) / (2 * a);
+                                lt = (t1 > 0) ? t1 : t2;
+                                acc = lt < 1E10;
+                                if (lt == 0) lt = 0.0; /* -0.0: the bit pattern must order like the value */
+                            }
+                        }
+                    }
+                    (void)beta; (void)gamma; (void)tv;
+                } else {
+                tv = tri_load(tri_base, ok ? tri : 0u);
                 asm volatile("" ::: "memory");
                 pin3(tv.A); pin3(tv.e1); pin3(tv.e2); pin3(rc); pin3(ru);
                 if (CNT && RT_STAMP_STEPS) {
@@ -922,6 +884,8 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
                         acc = false;
                         atomicMin(&w->best_pos[rl], RT_PHANTOM_BASE + (own ? 0 : sc.tris[tri].mesh));
                     }
+                }
+                key = own ? tv.id : (int32_t)tri;
                 }
                 if (__ballot(acc) != 0ull) {
                     /* keep (min t, then min position) per ray. LDS executes one wave's instructions in
@@ -941,7 +905,7 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
                         }
                     }
                     wave_sync();
-                    if (mine) atomicMin(&w->best_pos[rl], own ? tv.id : (int32_t)tri); /* position in the reference's order */
+                    if (mine) atomicMin(&w->best_pos[rl], key);
                 }
                 wave_sync();
                 if (CNT) { uint64_t t = RT_STAMP(); cnt.cyc_leaf += t - st0; st0 = t; cnt.leaf_steps++; cnt.leaf_lanes += (uint64_t)k; }
@@ -965,7 +929,8 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
                     atomicOr(sc.overflow, 2);
                 }
                 if (!have) rec = 0;
-                const float4 *rp = reinterpret_cast<const float4 *>(sc.own_rec4 + rec);
+                if (CNT && SPHP && have) cnt.sph_nodes += 4; /* four box tests per record */
+                const float4 *rp = reinterpret_cast<const float4 *>(tree4 + rec);
                 const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3], q4 = rp[4], q5 = rp[5];
                 const uint4 ch = *reinterpret_cast<const uint4 *>(rp + 6);
                 if (CNT && RT_STAMP_STEPS) { /* the record has arrived */
@@ -1057,6 +1022,75 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
     }
 }
 
+/* The pool's tables for one ray before a traversal: the ray, the constants of the single-precision box test, and the
+ * hit known so far - t0 (nothing at or beyond it can matter) with `pos` as the object / position that holds it, or
+ * INT32_MAX for none. */
+__device__ __forceinline__ void table_begin(const DScene &sc, WaveLDS *w, int slot, const RayQ &q, bool prune, double t0, int32_t pos, bool never_skip) {
+    const RayK k = ray_constants(sc, q.C, q.u);
+    w->ray[0][slot] = q.C.x; w->ray[1][slot] = q.C.y; w->ray[2][slot] = q.C.z;
+    w->ray[3][slot] = q.u.x; w->ray[4][slot] = q.u.y; w->ray[5][slot] = q.u.z;
+    w->rayf[0][slot] = (float)k.iu.x; w->rayf[1][slot] = (float)k.iu.y; w->rayf[2][slot] = (float)k.iu.z;
+    w->rayf[3][slot] = (float)k.nc.x; w->rayf[4][slot] = (float)k.nc.y; w->rayf[5][slot] = (float)k.nc.z;
+    const float tf = (float)(k.tol * RT_TOLF_SCALE);
+    w->tolf[slot] = (q.anyhit && prune) ? -tf : tf; /* the sign bit of a NaN is kept too */
+    w->best_t[slot] = (unsigned long long)__double_as_longlong(t0);
+    w->best_pos[slot] = pos;
+    w->thrf[slot] = (prune && !never_skip) ? upper_float(t0 * RT_PRUNE_SLACK) : __builtin_huge_valf();
+}
+
+/* Long sphere lists: the closest sphere of a lane's two rays through the wave's pool (pool_traverse<CNT, true>). The few
+ * spheres far larger than the rest (the walls) are tested by every lane first, which gives the traversal a distance to
+ * prune with; the rest are reached through the tree over their boxes, 64 (ray, record) or (ray, sphere) pairs per step
+ * whichever rays they belong to. The winner is Scene::intersect's: the choice among tested spheres (smallest t, then
+ * smallest objectId) does not depend on their order, and a sphere that is skipped - box certainly missed, or wholly
+ * behind what is known, or beyond tmax - cannot be it. Rays outside the tree's reach are left to ray_begin (done_*
+ * stays false). */
+template <bool CNT, typename SP>
+__device__ __forceinline__ void spheres_pool(const DScene &sc, const DScene &cold, WaveLDS *w, SP sph, const RayQ &qa, const RayQ &qb, HitRec &ha, HitRec &hb,
+                                             bool &done_a, bool &done_b, Cnt &cnt, uint64_t &st0) {
+    const int lane = lane_id();
+    hit_none(ha);
+    hit_none(hb);
+    done_a = qa.active && sphere_walk_ok(cold, qa.C);
+    done_b = qb.active && sphere_walk_ok(cold, qb.C);
+    const unsigned long long mask_a = wave_ballot(done_a), mask_b = wave_ballot(done_b);
+    if ((mask_a | mask_b) == 0ull) return;
+    const int n_big = uni(cold.n_sph_big);
+    for (int s = 0; s < n_big; s++) {
+        if (done_a) sphere_test_counted(sph, s, qa.C, qa.u, ha);
+        if (done_b) sphere_test_counted(sph, s, qb.C, qb.u, hb);
+    }
+    const RayQ *const q[2] = {&qa, &qb};
+    HitRec *const h[2] = {&ha, &hb};
+    const bool done[2] = {done_a, done_b};
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        if (!done[r]) continue;
+        /* spheres count below t0 = min(1E10, the hit so far, tmax); the hit so far is entered as the holder of t0 when it is */
+        double t0 = 1E10;
+        if (h[r]->t < t0) t0 = h[r]->t;
+        if (q[r]->tmax < t0) t0 = q[r]->tmax;
+        if (!(t0 > 0)) t0 = 0;
+        const bool holds = h[r]->obj != INT32_MAX && h[r]->t == t0;
+        table_begin(cold, w, lane + r * RT_WAVE, *q[r], true, t0, holds ? h[r]->obj : INT32_MAX, false);
+    }
+    wave_sync();
+    pool_traverse<CNT, true>(sc, cold, w, nullptr, true, true, mask_a, mask_b, cnt, st0);
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        if (!done[r]) continue;
+        const int slot = lane + r * RT_WAVE;
+        const int32_t oid = w->best_pos[slot];
+        if (oid != INT32_MAX && oid != h[r]->obj) { /* a sphere of the tree is closer (or as close, with a lower objectId) */
+            h[r]->t = __longlong_as_double((long long)w->best_t[slot]);
+            h[r]->obj = oid;
+            h[r]->prim = in_global(cold.sph_of_obj)[oid];
+            h[r]->mesh = -1;
+        }
+    }
+    wave_sync();
+}
+
 /* Scene::intersect, raytracer.cpp:930-951, for up to two rays per lane (slots lane and 64 + lane). Called by all
  * 64 lanes together; active rays get their closest hit. */
 /* SPH: compiled with the walk through the sphere tree (scenes with long sphere lists); without it the code for short
@@ -1080,7 +1114,7 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScen
     bool kept = false, redo_a = false, redo_b = false;
   for (;;) {
     bool sa = false, sb = false;
-    if (SPH && cold.sph_nodes != nullptr && prune) spheres_walk2(cold, sph, qa, qb, ha, hb, sa, sb);
+    if (SPH && cold.sph_rec4 != nullptr && prune) spheres_pool<CNT>(sc, cold, w, sph, qa, qb, ha, hb, sa, sb, cnt, st0);
     ray_begin<CNT, SPH>(cold, w, sph, lane, qa, prune, sa, ha, cnt);
     ray_begin<CNT, SPH>(cold, w, sph, RT_WAVE + lane, qb, prune, sb, hb, cnt);
     if (CNT) { const uint64_t t = RT_STAMP(); cnt.cyc_roots += t - st0; st0 = t; } /* spheres and ray constants count with the roots */

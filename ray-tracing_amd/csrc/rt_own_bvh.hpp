@@ -234,13 +234,13 @@ struct Builder {
     }
 };
 
+inline Built build_boxes(const std::vector<Bounds> &tb);
+
+/* the tree over triangles */
 inline Built build(const rt_tri *tris, int64_t n) {
-    Built out;
-    if (n <= 0) return out;
+    if (n <= 0) return Built();
     const int threads = host_threads();
     std::vector<Bounds> tb((size_t)n);
-    std::vector<double> cen((size_t)n * 3);
-    std::vector<int32_t> idx((size_t)n);
     std::vector<char> bad((size_t)threads, 0);
     parallel_parts(n, n >= (1 << 16) ? threads : 1, [&](int p, int64_t b0, int64_t e0) {
         for (int64_t k = b0; k < e0; k++) {
@@ -253,13 +253,28 @@ inline Built build(const rt_tri *tris, int64_t n) {
                     if (v[q] < b.lo[a]) b.lo[a] = v[q];
                     if (v[q] > b.hi[a]) b.hi[a] = v[q];
                 }
-                cen[(size_t)k * 3 + a] = 0.5 * (b.lo[a] + b.hi[a]);
             }
-            idx[(size_t)k] = (int32_t)k;
         }
     });
     for (char x : bad)
-        if (x) return out;
+        if (x) return Built();
+    return build_boxes(tb);
+}
+
+/* the tree over any primitives, given their (finite) boxes: triangles, or the spheres of a long sphere list */
+inline Built build_boxes(const std::vector<Bounds> &tb) {
+    Built out;
+    const int64_t n = (int64_t)tb.size();
+    if (n <= 0) return out;
+    const int threads = host_threads();
+    std::vector<double> cen((size_t)n * 3);
+    std::vector<int32_t> idx((size_t)n);
+    parallel_parts(n, n >= (1 << 16) ? threads : 1, [&](int, int64_t b0, int64_t e0) {
+        for (int64_t k = b0; k < e0; k++) {
+            for (int a = 0; a < 3; a++) cen[(size_t)k * 3 + a] = 0.5 * (tb[(size_t)k].lo[a] + tb[(size_t)k].hi[a]);
+            idx[(size_t)k] = (int32_t)k;
+        }
+    });
     Builder B{tb, cen, idx};
     if (n <= kLeaf) { /* a tree needs one record: both children are leaves (the right one may be empty) */
         rtd::NodeRec32 r;
