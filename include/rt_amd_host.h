@@ -26,8 +26,13 @@ rth_mesh *rth_mesh_create(const double albedo[3], int mirror, int transp);
 void rth_mesh_destroy(rth_mesh *m);
 /* TriangleMesh::readOBJ, raytracer.cpp:293 (a missing file is an error, not a crash) */
 int rth_mesh_read_obj(rth_mesh *m, const char *path);
-/* TriangleMesh::loadTexture, raytracer.cpp:759, for binary PPM files */
+/* TriangleMesh::loadTexture, raytracer.cpp:759: JPEG files (baseline and progressive; the texels stbi_load(..., 3) of the
+ * reference's stb_image v2.26 gives, raytracer.cpp:762) and binary PPM files */
 int rth_mesh_load_texture(rth_mesh *m, const char *path);
+/* texture k of the mesh as loadTexture / addTexture stored it: size, and (rgb != NULL) its W*H*3 bytes */
+int rth_mesh_texture(const rth_mesh *m, int32_t k, int32_t *W, int32_t *H, uint8_t *rgb);
+/* the JPEG decoder of loadTexture on a file image in memory; rgb (may be NULL to ask for the size) receives W*H*3 bytes */
+int rth_decode_jpeg(const uint8_t *file, int64_t n, int32_t *W, int32_t *H, uint8_t *rgb, int64_t rgb_cap);
 /* a decoded RGB8 image, rows top to bottom, as stbi_load(...,3) returns it (raytracer.cpp:762) */
 int rth_mesh_add_texture(rth_mesh *m, const uint8_t *rgb, int32_t W, int32_t H);
 /* fill vertices / normals / uvs (2 per uv) / TriangleIndices (10 ints each, member order

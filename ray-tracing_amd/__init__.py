@@ -56,7 +56,7 @@ RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt
               "rt_accum_download", "rt_accum_upload", "rt_accum_device_ptr", "rt_accum_add", "rt_resolve", "rt_intersect_rays", "rt_sample_radiance", "rt_sample_trace",
               "rt_get_counters", "rt_reset_counters", "rt_last_render_ms", "rt_render_time_ms", "rt_stream", "rt_version", "rt_build_bvh"]
 RTH_SYMBOLS = ["rth_last_error", "rth_mesh_create", "rth_mesh_destroy", "rth_mesh_read_obj", "rth_mesh_load_texture",
-               "rth_mesh_add_texture", "rth_mesh_set_raw", "rth_mesh_op", "rth_mesh_build_bvh", "rth_mesh_build_bvh_device", "rth_mesh_sizes",
+               "rth_mesh_add_texture", "rth_mesh_texture", "rth_decode_jpeg", "rth_mesh_set_raw", "rth_mesh_op", "rth_mesh_build_bvh", "rth_mesh_build_bvh_device", "rth_mesh_sizes",
                "rth_mesh_get", "rth_mesh_bvh_dump", "rth_scene_create", "rth_scene_destroy", "rth_scene_add_sphere",
                "rth_scene_add_mesh", "rth_scene_upload", "rth_scene_render_devices", "rth_scene_flat_info", "rth_camera_make", "rth_params_default",
                "rth_write_png", "rth_write_execution_time"]
@@ -99,6 +99,8 @@ _sig("rth_mesh_destroy", None, _vp)
 _sig("rth_mesh_read_obj", C.c_int, _vp, C.c_char_p)
 _sig("rth_mesh_load_texture", C.c_int, _vp, C.c_char_p)
 _sig("rth_mesh_add_texture", C.c_int, _vp, _vp, _i32, _i32)
+_sig("rth_mesh_texture", C.c_int, _vp, _i32, C.POINTER(_i32), C.POINTER(_i32), _vp)
+_sig("rth_decode_jpeg", C.c_int, _vp, _i64, C.POINTER(_i32), C.POINTER(_i32), _vp, _i64)
 _sig("rth_mesh_set_raw", C.c_int, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp)
 _sig("rth_mesh_op", C.c_int, _vp, C.c_int, C.c_int, C.c_int, _dbl)
 _sig("rth_mesh_build_bvh", C.c_int, _vp)
@@ -193,15 +195,16 @@ class TriangleMesh:
         return self
 
     def loadTexture(self, path):
-        """PPM goes through the C++ loader; anything else is decoded here (PIL) to RGB8 first.
-        The reference decodes with stb_image (raytracer.cpp:762); decoders differ by a few levels."""
-        if str(path).lower().endswith(".ppm"):
-            _host_check(lib.rth_mesh_load_texture(self._h, os.fsencode(path)))
-            from PIL import Image
-            self.textures.append(np.asarray(Image.open(path).convert("RGB"), np.uint8))
-            return self
-        from PIL import Image
-        return self.addTexture(np.asarray(Image.open(path).convert("RGB"), np.uint8))
+        """TriangleMesh::loadTexture (raytracer.cpp:759-766) through the C++ loader: JPEG files with the texels of the
+        reference's stbi_load call (:762), binary PPM files as they are."""
+        _host_check(lib.rth_mesh_load_texture(self._h, os.fsencode(path)))
+        k = len(self.textures)
+        W, H = _i32(), _i32()
+        _host_check(lib.rth_mesh_texture(self._h, k, C.byref(W), C.byref(H), None))
+        rgb = np.empty((H.value, W.value, 3), np.uint8)
+        _host_check(lib.rth_mesh_texture(self._h, k, C.byref(W), C.byref(H), _ptr(rgb)))
+        self.textures.append(rgb)
+        return self
 
     def _op(self, name, a=0, b=0, angle=0.0):
         _host_check(lib.rth_mesh_op(self._h, OPS[name], int(a), int(b), float(angle)))
@@ -442,6 +445,16 @@ def render_devices(scene, cam, W, H, spp, devices, seed=10, flags=0):
         return out
     finally:
         lib.rth_scene_destroy(h)
+
+
+def decode_jpeg(data):
+    """the loader's JPEG decoder on the bytes of a file: (H, W, 3) uint8"""
+    buf = np.frombuffer(bytes(data), np.uint8)
+    W, H = _i32(), _i32()
+    _host_check(lib.rth_decode_jpeg(_ptr(buf), buf.size, C.byref(W), C.byref(H), None, 0))
+    out = np.empty((H.value, W.value, 3), np.uint8)
+    _host_check(lib.rth_decode_jpeg(_ptr(buf), buf.size, C.byref(W), C.byref(H), _ptr(out), out.size))
+    return out
 
 
 def version():

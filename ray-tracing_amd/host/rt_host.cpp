@@ -153,6 +153,35 @@ void TriangleMesh::addTexture(const uint8_t *rgb, int W, int H) {
 void TriangleMesh::loadTexture(const char *filename) {
     FILE *f = fopen(filename, "rb");
     if (!f) throw std::runtime_error(std::string("loadTexture: cannot open ") + filename);
+    {
+        /* JPEG, what the reference's scenes use (raytracer.cpp:1223, :1244, ...): decoded with the arithmetic of the
+         * reference's stbi_load(..., 3) call (:762), texel for texel (rt_jpeg.cpp) */
+        uint8_t head[3] = {0, 0, 0};
+        const size_t got = fread(head, 1, 3, f);
+        if (looksLikeJPEG(head, got)) {
+            std::vector<uint8_t> file;
+            fseek(f, 0, SEEK_END);
+            const long sz = ftell(f);
+            fseek(f, 0, SEEK_SET);
+            bool ok = sz > 0;
+            if (ok) {
+                file.resize((size_t)sz);
+                ok = fread(file.data(), 1, file.size(), f) == file.size();
+            }
+            fclose(f);
+            if (!ok) throw std::runtime_error(std::string("loadTexture: cannot read ") + filename);
+            std::vector<uint8_t> rgb;
+            int W = 0, H = 0;
+            try {
+                decodeJPEG(file.data(), file.size(), rgb, W, H);
+            } catch (const std::exception &e) {
+                throw std::runtime_error(std::string("loadTexture: ") + filename + ": " + e.what());
+            }
+            addTexture(rgb.data(), W, H);
+            return;
+        }
+        fseek(f, 0, SEEK_SET);
+    }
     int W = 0, H = 0, maxv = 0;
     char magic[3] = {0, 0, 0};
     bool ok = fscanf(f, "%2s", magic) == 1 && magic[0] == 'P' && magic[1] == '6';
@@ -175,7 +204,7 @@ void TriangleMesh::loadTexture(const char *filename) {
         ok = false;
     }
     fclose(f);
-    if (!ok) throw std::runtime_error(std::string("loadTexture: not a binary PPM (P6, maxval 255): ") + filename +
+    if (!ok) throw std::runtime_error(std::string("loadTexture: neither a JPEG file nor a binary PPM (P6, maxval 255): ") + filename +
                                       " - decode other formats to RGB8 and use addTexture");
     addTexture(buf.data(), W, H);
 }
@@ -714,6 +743,29 @@ void rth_mesh_destroy(rth_mesh *m) { delete m; }
 int rth_mesh_read_obj(rth_mesh *m, const char *path) { RTH_TRY(m->m.readOBJ(path)) }
 int rth_mesh_load_texture(rth_mesh *m, const char *path) { RTH_TRY(m->m.loadTexture(path)) }
 int rth_mesh_add_texture(rth_mesh *m, const uint8_t *rgb, int32_t W, int32_t H) { RTH_TRY(m->m.addTexture(rgb, W, H)) }
+int rth_mesh_texture(const rth_mesh *m, int32_t k, int32_t *W, int32_t *H, uint8_t *rgb) {
+    RTH_TRY({
+        if (!m || k < 0 || (size_t)k >= m->m.textures.size()) throw std::runtime_error("rth_mesh_texture: no such texture");
+        if (W) *W = m->m.Wtex[(size_t)k];
+        if (H) *H = m->m.Htex[(size_t)k];
+        if (rgb) memcpy(rgb, m->m.textures[(size_t)k].data(), m->m.textures[(size_t)k].size());
+    })
+}
+int rth_decode_jpeg(const uint8_t *file, int64_t n, int32_t *W, int32_t *H, uint8_t *rgb, int64_t rgb_cap) {
+    RTH_TRY({
+        if (!file || n <= 0 || !W || !H) throw std::runtime_error("rth_decode_jpeg: bad argument");
+        std::vector<uint8_t> out;
+        int w = 0;
+        int h = 0;
+        rt::decodeJPEG(file, (size_t)n, out, w, h);
+        *W = w;
+        *H = h;
+        if (rgb) {
+            if ((int64_t)out.size() > rgb_cap) throw std::runtime_error("rth_decode_jpeg: output buffer too small");
+            memcpy(rgb, out.data(), out.size());
+        }
+    })
+}
 
 int rth_mesh_set_raw(rth_mesh *h, int64_t nv, const double *v, int64_t nn, const double *n, int64_t nuv, const double *uv, int64_t nt,
                      const int32_t *idx10) {

@@ -202,6 +202,12 @@ void render(const Scene &scene, const Camera &cam, const RenderParams &p, std::v
 /* the same for callers that hold the flattened scene and the PODs: p.spp samples from p.spp_offset on, rgb8 = W*H*3 bytes */
 void renderDevices(const rt_scene_desc &d, const rt_camera &cam, const rt_params &p, const int *devices, int n_devices, uint8_t *rgb8);
 
+/* JPEG decoding with the arithmetic of the reference's stbi_load(file, &W, &H, &c, 3) call (raytracer.cpp:762): the same
+ * texels as that library gives, baseline and progressive (rt_jpeg.cpp). rgb receives W*H*3 bytes, rows top to bottom.
+ * Throws std::runtime_error on files it cannot decode. */
+void decodeJPEG(const uint8_t *data, size_t n, std::vector<uint8_t> &rgb, int &W, int &H);
+bool looksLikeJPEG(const uint8_t *data, size_t n);
+
 /* The output step of main(), raytracer.cpp:1505-1512. writePNG stores an 8-bit RGB image (rows top to bottom, as
  * Renderer::render returns it) as a PNG file: the same pixels as the reference's stbi_write_png call, in an
  * uncompressed zlib stream (any decoder reads it; the encoder is this library's own). writeExecutionTime writes the

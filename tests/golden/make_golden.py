@@ -166,6 +166,19 @@ def main():
     out["reader_normals"] = n2
     out["reader_uvs"] = uv2
     out["reader_idx"] = ix2
+    # Texels of the reference's 13 texture files as its own loader decodes them (TriangleMesh::loadTexture ->
+    # stbi_load(..., 3), raytracer.cpp:759-766): size and SHA-256 of the RGB8 image, keyed by the path under objects/.
+    import glob
+    import json
+    tex = {}
+    for f in sorted(glob.glob("/root/reference/objects/**/*.jpg", recursive=True)):
+        t = ob.TrueRefScene([dict(kind="mesh", verts=np.zeros((3, 3)), normals=np.zeros((3, 3)), uvs=np.zeros((3, 2)), idx=np.zeros((1, 10), np.int32),
+                                  albedo=(1, 1, 1), mirror=False, transp=False, texture_paths=[f])], 1.0, (0, 0, 0), build_bvh=False)
+        img = t.mesh_texture(0, 0)
+        tex[os.path.relpath(f, "/root/reference/objects")] = dict(W=int(img.shape[1]), H=int(img.shape[0]), sha256=sha(img),
+                                                                  file_sha256=hashlib.sha256(open(f, "rb").read()).hexdigest())
+    json.dump(tex, open(os.path.join(HERE, "texture_sha256.json"), "w"), indent=1, sort_keys=True)
+    print("wrote texture_sha256.json:", len(tex), "textures")
     np.savez_compressed(os.path.join(HERE, "reference_outputs.npz"), **out)
     print("wrote", os.path.join(HERE, "reference_outputs.npz"), os.path.getsize(os.path.join(HERE, "reference_outputs.npz")), "bytes")
 

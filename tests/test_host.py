@@ -154,3 +154,62 @@ def test_png_and_execution_time_output(rta, tmp_path):
     with pytest.raises(rta.RTError):
         rta.write_png(str(tmp_path / "no_such_dir" / "x.png"), np.zeros((2, 2, 3), np.uint8))
 
+
+
+def _jpeg_cases(tmp_path):
+    """JPEG files of every layout the decoder handles, written with PIL: sampling 4:4:4 / 4:2:2 / 4:2:0, baseline and
+    progressive, restart intervals, optimised tables, grey, sizes that are not multiples of the MCU"""
+    from PIL import Image
+    rng = np.random.default_rng(7)
+    cases = []
+    for k, (w, h) in enumerate([(64, 48), (37, 23), (129, 65), (16, 16), (1, 1), (9, 200)]):
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.stack([(xx * 5 + yy * 3) % 256, (xx * xx + 7 * yy) % 256, (255 - 2 * xx + yy * yy // 3) % 256], -1).astype(np.uint8)
+        img = np.where(rng.random((h, w, 1)) < 0.2, rng.integers(0, 256, (h, w, 3)), img).astype(np.uint8)
+        for sub in (0, 1, 2):
+            for prog in (False, True):
+                for extra in ({}, {"optimize": True}, {"restart_marker_blocks": 3}):
+                    name = tmp_path / ("c%d_s%d_p%d_%s.jpg" % (k, sub, prog, "_".join(extra) or "plain"))
+                    Image.fromarray(img).save(name, "JPEG", quality=[35, 75, 92][(k + sub) % 3], subsampling=sub, progressive=prog, **extra)
+                    cases.append(str(name))
+        name = tmp_path / ("c%d_grey.jpg" % k)
+        Image.fromarray(img[:, :, 0]).save(name, "JPEG", quality=80)
+        cases.append(str(name))
+    return cases
+
+
+def test_jpeg_decoder_equals_the_reference_decoder(rta, ob, tmp_path):
+    """TriangleMesh::loadTexture on JPEG files: every texel equal to what the reference's own loader (stbi_load(..., 3),
+    raytracer.cpp:762) returns, on generated files of every layout"""
+    if not ob.have_trueref():
+        pytest.skip("oracle/_ref not built")
+    stub = dict(kind="mesh", verts=np.zeros((3, 3)), normals=np.zeros((3, 3)), uvs=np.zeros((3, 2)), idx=np.zeros((1, 10), np.int32),
+                albedo=(1, 1, 1), mirror=False, transp=False)
+    cases = _jpeg_cases(tmp_path)
+    assert len(cases) > 100
+    for f in cases:
+        ref = ob.TrueRefScene([dict(stub, texture_paths=[f])], 1.0, (0, 0, 0), build_bvh=False).mesh_texture(0, 0)
+        got = rta.TriangleMesh().loadTexture(f).textures[0]
+        assert got.shape == ref.shape and np.array_equal(got, ref), f
+    with pytest.raises(rta.RTError):
+        rta.decode_jpeg(open(cases[0], "rb").read()[:200])  # truncated
+    with pytest.raises(rta.RTError):
+        rta.decode_jpeg(b"\xff\xd8\xff\xd9")  # no frame
+
+
+def test_reference_textures_decode_to_the_reference_texels(rta):
+    """the 13 JPEG textures of the reference's scenes (raytracer.cpp:1223, :1244, ...): SHA-256 of the decoded image equal to
+    the fixture made from the reference's own loader (tests/golden/make_golden.py). The files are third-party assets and
+    exist only where the reference tree does."""
+    import json
+    fix = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "texture_sha256.json")))
+    assert len(fix) == 13
+    root = "/root/reference/objects"
+    if not os.path.isdir(root):
+        pytest.skip("the reference's assets are not on this machine")
+    for rel, want in fix.items():
+        data = open(os.path.join(root, rel), "rb").read()
+        assert hashlib.sha256(data).hexdigest() == want["file_sha256"], rel
+        img = rta.decode_jpeg(data)
+        assert img.shape == (want["H"], want["W"], 3), rel
+        assert hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == want["sha256"], rel
