@@ -289,6 +289,15 @@ def main():
                    "sample": "same scene and frame, %d of %d spp (%.1f s of CPU work on %d OpenMP threads, schedule(dynamic,1) rows); "
                              "oracle/ref_cpu.cpp with the counter-based RNG (the reference's one shared engine makes its threads wait for each other)" % (cpu_spp, spp_image, dt, threads),
                    "setup_s": round(t2 - t1, 2)}
+            # the reference itself, as committed: its one global random engine shared by all OpenMP threads and rand()
+            # (raytracer.cpp:26-27, :1006, :1456) - built from the reference's own source where that exists
+            # (oracle/_ref/libref_plain.so travels with the tree). Only the committed estimator exists in it (flags == 0).
+            if flags == 0:
+                ref_spp = max(1, cpu_spp // 6)
+                dt_ref = ob.time_plain_reference(scenes.export_objects(scene), scene.I, scene.L, cam, rta.make_params(W, H, ref_spp, flags=0), threads)
+                if dt_ref:
+                    cpu["reference_shared_rng"] = {"value": round(W * H * ref_spp / dt_ref / 1e6, 4), "unit": "Mpaths/s", "cores": threads, "kind": "reference",
+                                                   "sample": "%d spp, %.1f s: /root/reference/raytracer.cpp's own classes, OpenMP rows, shared engine(10) + rand() as committed" % (ref_spp, dt_ref)}
         out = {"metric": "Mpaths/s (whole node) final scene 1024x1024" if args.config == "cfg4" else "Mpaths/s (whole node) %s %dx%d" % (args.config, W, H),
                "value": round(value, 3), "unit": "Mpaths/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),

@@ -16,6 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_LIB = os.path.join(_HERE, "libref_cpu.so")
 TRUEREF_LIB = os.path.join(_HERE, "_ref", "libref_true.so")
+PLAINREF_LIB = os.path.join(_HERE, "_ref", "libref_plain.so")  # the reference with its own shared RNG: for timing only
 
 _vp, _i32, _i64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 _pd = C.POINTER(C.c_double)
@@ -64,10 +65,10 @@ def _load_oracle():
     return lib
 
 
-def _load_trueref():
-    if not os.path.exists(TRUEREF_LIB):
+def _load_trueref(path=TRUEREF_LIB):
+    if not os.path.exists(path):
         return None
-    lib = C.CDLL(TRUEREF_LIB)
+    lib = C.CDLL(path)
     lib.trf_scene_create.restype = _vp
     lib.trf_scene_create.argtypes = [_dbl, _pd]
     lib.trf_scene_destroy.argtypes = [_vp]
@@ -87,6 +88,7 @@ def _load_trueref():
     lib.trf_intersect_rays.argtypes = [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]
     lib.trf_sample_radiance.argtypes = [_vp, _vp, _vp, _vp, _i64, _vp]
     lib.trf_render.argtypes = [_vp, _vp, _vp, _vp]
+    lib.trf_render_omp.argtypes = [_vp, _vp, _vp, _vp, C.c_int]
     lib.trf_resolve.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp]
     lib.trf_camera_basis.argtypes = [_dbl, _dbl, _dbl, C.c_int, _pd, _pd, _pd, _pd]
     lib.trf_draws.restype = C.c_uint64
@@ -227,6 +229,29 @@ def resolve(accum, spp_total):
     out = np.empty((H, W, 3), np.uint8)
     orc.orc_resolve(_ptr(accum), W, H, float(spp_total), _ptr(out))
     return out
+
+
+def time_plain_reference(objects, I, L, cam, params, n_threads):
+    """Wall seconds of the REAL reference's pixel loop (OpenMP rows, its own shared random engine and rand(): the
+    program as committed) on an exported object list, or None where oracle/_ref/libref_plain.so is absent. The values it
+    renders are not deterministic with several threads and are not used."""
+    import time
+    lib = _load_trueref(PLAINREF_LIB)
+    if lib is None:
+        return None
+    global trf
+    keep, trf = trf, lib  # TrueRefScene drives whichever library `trf` names
+    try:
+        t = TrueRefScene(objects, I, L)
+        acc = np.zeros((params.H, params.W, 3))
+        t0 = time.time()
+        rc = lib.trf_render_omp(t._h, C.byref(cam), C.byref(params), _ptr(acc), int(n_threads))
+        dt = time.time() - t0
+        assert rc == 0 and np.isfinite(acc).any()
+        del t
+        return dt
+    finally:
+        trf = keep
 
 
 class TrueRefScene:

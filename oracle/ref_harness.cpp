@@ -63,13 +63,20 @@ struct InjEngine {
 } // namespace std
 static int inj_rand() { return (int)(h_draw() >> 33); }
 
+/* TRF_PLAIN (oracle/_ref/libref_plain.so): no substitution at all - the reference's own global engine(10) shared by all
+ * OpenMP threads and libc's rand(), as committed (raytracer.cpp:26-27, :1006). Not deterministic with more than one
+ * thread; built only to TIME the reference faithfully (trf_render_omp), never to compare values. */
+#ifndef TRF_PLAIN
 #define default_random_engine InjEngine
 #define rand inj_rand
+#endif
 #define main reference_main
 #include "/root/reference/raytracer.cpp"
 #undef main
+#ifndef TRF_PLAIN
 #undef rand
 #undef default_random_engine
+#endif
 
 struct trf_scene {
     Scene scene;
@@ -336,6 +343,26 @@ int trf_sample_radiance(trf_scene *s, const rt_camera *cam, const rt_params *p, 
         Vector c = sample_one(s, cam, p, ijk[3 * q], ijk[3 * q + 1], ijk[3 * q + 2]);
         out[3 * q] = c[0]; out[3 * q + 1] = c[1]; out[3 * q + 2] = c[2];
     }
+    return 0;
+}
+
+/* The pixel loop as the reference runs it: rows in parallel, schedule(dynamic, 1) (raytracer.cpp:1456-1457), every thread
+ * drawing from whatever random source this build has. With TRF_PLAIN that is the reference's single shared engine. */
+int trf_render_omp(trf_scene *s, const rt_camera *cam, const rt_params *p, double *accum, int n_threads) {
+    if (p->flags != 0 || p->max_rebond != 10 || p->ior != 1.4 || p->epsilon != 0.00001 || p->shadow_bias != 0.0001) return -1;
+#ifndef TRF_PLAIN
+    if (n_threads != 1) return -2; /* the injected stream is one global cursor: single-threaded only */
+#endif
+    int j0 = p->rect[0], i0 = p->rect[1], j1 = p->rect[2], i1 = p->rect[3];
+    if (!j0 && !i0 && !j1 && !i1) { j1 = p->W; i1 = p->H; }
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+    for (int i = i0; i < i1; i++)
+        for (int j = j0; j < j1; j++) {
+            double *px = accum + ((int64_t)i * p->W + j) * 3;
+            Vector color(px[0], px[1], px[2]);
+            for (int k = 0; k < p->spp; k++) color += sample_one(s, cam, p, i, j, p->spp_offset + k);
+            px[0] = color[0]; px[1] = color[1]; px[2] = color[2];
+        }
     return 0;
 }
 
