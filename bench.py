@@ -265,7 +265,7 @@ def main():
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r2_%s_mem2.json" % args.config)))
             if pm.get("lib_sha16") == lib_sha16(rta.LIB_PATH) and pm.get("spp_step") == spp_step and pm.get("size") == W:
-                kk = [k for k in pm["kernels"] if k.startswith(kname.split("<")[0])][0]
+                kk = [k for k in pm["kernels"] if kname in k][0]
                 roofline["traffic"] = round(pm["kernels"][kk]["FETCH_SIZE"] * 1024.0 * 2.0 / pm["kernels"][kk]["dispatches"], 1)
                 roofline["traffic_note"] = "HBM-side fetch bytes per launch from profiles/r2_%s_mem2.json (same library build), x2 gfx950 correction" % args.config
         except (OSError, KeyError, IndexError, ValueError, ZeroDivisionError):
