@@ -170,6 +170,15 @@ __global__ void rt_units_add_kernel(double *accum, const double *unit_sums, int 
 }
 
 /* dst += src over n doubles: the sum of two devices' sample ranges (rt_accum_add) */
+/* the filter tree's triangles: out[k] = tris[pos[k]], with orig_id = pos[k], the position in the reference's order */
+__global__ void rt_gather_tris_kernel(const rt_tri *tris, const int32_t *pos, uint32_t n, rt_tri *out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    rt_tri t = tris[pos[k]];
+    t.orig_id = pos[k];
+    out[k] = t;
+}
+
 __global__ void rt_accum_add_kernel(double *dst, const double *src, int64_t n) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) dst[t] = dst[t] + src[t];
@@ -497,22 +506,10 @@ static bool build_sphere_tree(const rt_sphere *sph, int n, std::vector<rt_sphere
     return true;
 }
 
-/* wall-clock stamps of rt_upload_scene's stages, printed to stderr when RT_UPLOAD_TIMING is set in the environment */
-struct StageClock {
-    bool on;
-    std::chrono::steady_clock::time_point t0;
-    StageClock() : on(getenv("RT_UPLOAD_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
-    void mark(const char *what) {
-        if (!on) return;
-        const auto t1 = std::chrono::steady_clock::now();
-        fprintf(stderr, "rt_upload_scene: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
-        t0 = t1;
-    }
-};
-
 int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
     if (!c) return RT_E_INVALID;
-    StageClock clk;
+    rtown::stage_tick(nullptr);
+    rtown::PoolScope pool(rtown::host_threads()); /* the caller's, when it has one already */
     if (!s) return fail(c, RT_E_INVALID, "rt_upload_scene: scene is NULL");
     if (s->n_spheres < 0 || s->n_meshes < 0 || s->n_nodes < 0 || s->n_tris < 0 || s->n_tex < 0)
         return fail(c, RT_E_INVALID, "rt_upload_scene: negative count");
@@ -587,7 +584,7 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
         if (tx.W <= 0 || tx.H <= 0 || tx.offset < 0 || tx.offset + (int64_t)tx.W * tx.H * 3 > s->texel_bytes)
             return fail(c, RT_E_INVALID, "texture %d: outside the texel pool", k);
     }
-    clk.mark("validation");
+    rtown::stage_tick("rt_upload_scene: validation");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_scene(c);
@@ -622,8 +619,8 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
     {
         /* device layouts (rt_device.hip.h): every BVH record as one float record plus two double halves */
         const int host_thr = rtown::host_threads();
-        std::vector<NodeHalf> halves((size_t)s->n_nodes * 2);
-        std::vector<NodeRec32> rec32((size_t)s->n_nodes);
+        rtown::raw_vector<NodeHalf> halves((size_t)s->n_nodes * 2);
+        rtown::raw_vector<NodeRec32> rec32((size_t)s->n_nodes);
         rtown::parallel_parts(s->n_nodes, s->n_nodes >= (1 << 16) ? host_thr : 1, [&](int, int64_t k0, int64_t k1) {
             for (int64_t k = k0; k < k1; k++) {
                 const rt_bvh_node &nd = s->nodes[k];
@@ -638,7 +635,7 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
                 rec32[(size_t)k].nL = nd.nL; rec32[(size_t)k].nR = nd.nR;
             }
         });
-        clk.mark("spheres, record repack");
+        rtown::stage_tick("rt_upload_scene: spheres, record repack");
         /* Extension records: the reference's builder leaves ranges of up to hundreds of triangles unsplit (:283). Such a
          * leaf is given a tree of its own over contiguous sub-ranges of its triangles (their order, which carries the
          * tie rule, is untouched). These boxes are a filter only - a ray is kept out of a sub-range just when it
@@ -710,66 +707,97 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
                 if (parts[t].depth > ext_depth) ext_depth = parts[t].depth;
             }
         }
-        clk.mark("extension records");
+        rtown::stage_tick("rt_upload_scene: extension records");
         /* The filter tree over the triangles of all meshes, and what confirms its winners: the reference leaf of every
          * triangle. A leaf whose box has no thickness along an axis is never entered by the reference (tMax > tMin cannot
          * hold, raytracer.cpp:184), so its triangles are left out of the filter tree: they cannot be part of any answer. */
+        if ((rc = upload_array(c, s->tris, (size_t)s->n_tris, &d.tris))) return rc;
         if (s->n_tris > 0) {
-            std::vector<int32_t> tri_leaf((size_t)s->n_tris, -1);
-            std::vector<float> leaf_box;
-            std::vector<char> leaf_flat;
-            auto add_leaf = [&](const double *box, int32_t first, int32_t count) {
-                const int32_t id = (int32_t)(leaf_box.size() / 6);
-                for (int a = 0; a < 6; a++) leaf_box.push_back((float)box[a]);
-                leaf_flat.push_back(box[0] == box[3] || box[1] == box[4] || box[2] == box[5]);
-                for (int32_t k = first; k < first + count; k++) tri_leaf[(size_t)k] = id;
-            };
+            struct LeafRef { const double *box; int32_t first, count; };
+            std::vector<LeafRef> leaves;
             for (int64_t k = 0; k < s->n_nodes; k++) {
-                if (s->nodes[k].nL > 0) add_leaf(s->nodes[k].boxL, s->nodes[k].L, s->nodes[k].nL);
-                if (s->nodes[k].nR > 0) add_leaf(s->nodes[k].boxR, s->nodes[k].R, s->nodes[k].nR);
+                if (s->nodes[k].nL > 0) leaves.push_back(LeafRef{s->nodes[k].boxL, s->nodes[k].L, s->nodes[k].nL});
+                if (s->nodes[k].nR > 0) leaves.push_back(LeafRef{s->nodes[k].boxR, s->nodes[k].R, s->nodes[k].nR});
             }
             for (int mi = 0; mi < s->n_meshes; mi++)
-                if (s->meshes[mi].root_count > 0) add_leaf(s->meshes[mi].root_box, s->meshes[mi].root, s->meshes[mi].root_count);
-            /* a triangle outside every leaf is never reached by the reference either */
-            std::vector<rt_tri> sub;
+                if (s->meshes[mi].root_count > 0) leaves.push_back(LeafRef{s->meshes[mi].root_box, s->meshes[mi].root, s->meshes[mi].root_count});
+            const int tri_thr = s->n_tris >= (1 << 16) ? host_thr : 1;
+            rtown::raw_vector<int32_t> tri_leaf((size_t)s->n_tris);
+            rtown::parallel_parts(s->n_tris, tri_thr, [&](int, int64_t k0, int64_t k1) { std::fill(tri_leaf.begin() + k0, tri_leaf.begin() + k1, -1); });
+            std::vector<float> leaf_box(leaves.size() * 6);
+            std::vector<char> leaf_flat(leaves.size());
+            std::vector<int64_t> part_sum((size_t)tri_thr, 0);
+            rtown::parallel_parts((int64_t)leaves.size(), tri_thr, [&](int p, int64_t l0, int64_t l1) {
+                for (int64_t id = l0; id < l1; id++) {
+                    const LeafRef &lf = leaves[(size_t)id];
+                    for (int a = 0; a < 6; a++) leaf_box[(size_t)id * 6 + a] = (float)lf.box[a];
+                    leaf_flat[(size_t)id] = lf.box[0] == lf.box[3] || lf.box[1] == lf.box[4] || lf.box[2] == lf.box[5];
+                    for (int32_t k = lf.first; k < lf.first + lf.count; k++) tri_leaf[(size_t)k] = (int32_t)id;
+                    part_sum[(size_t)p] += lf.count;
+                }
+            });
+            /* positions of the triangles that some leaf with a box of three non-zero extents holds (a triangle outside
+             * every leaf is never reached by the reference either), in ascending order */
+            rtown::raw_vector<int32_t> keep;
             {
-                std::vector<int32_t> keep;
-                keep.reserve((size_t)s->n_tris);
-                for (int64_t k = 0; k < s->n_tris; k++)
-                    if (tri_leaf[(size_t)k] >= 0 && !leaf_flat[(size_t)tri_leaf[(size_t)k]]) keep.push_back((int32_t)k);
-                sub.resize(keep.size());
-                rtown::parallel_parts((int64_t)keep.size(), keep.size() >= (1u << 16) ? host_thr : 1, [&](int, int64_t q0, int64_t q1) {
-                    for (int64_t q = q0; q < q1; q++) {
-                        sub[(size_t)q] = s->tris[keep[(size_t)q]];
-                        sub[(size_t)q].orig_id = keep[(size_t)q]; /* position in the reference's order */
-                    }
+                std::vector<int64_t> cnt((size_t)tri_thr + 1, 0), held((size_t)tri_thr, 0);
+                auto kept = [&](int64_t k) { return tri_leaf[(size_t)k] >= 0 && !leaf_flat[(size_t)tri_leaf[(size_t)k]]; };
+                rtown::parallel_parts(s->n_tris, tri_thr, [&](int p, int64_t k0, int64_t k1) {
+                    int64_t n = 0, h = 0;
+                    for (int64_t k = k0; k < k1; k++) { n += kept(k); h += tri_leaf[(size_t)k] >= 0; }
+                    cnt[(size_t)p + 1] = n;
+                    held[(size_t)p] = h;
+                });
+                int64_t in_leaves = 0, in_ranges = 0;
+                for (int p = 0; p < tri_thr; p++) { cnt[(size_t)p + 1] += cnt[(size_t)p]; in_leaves += held[(size_t)p]; in_ranges += part_sum[(size_t)p]; }
+                /* two leaves naming one triangle: the reference would test it under either box, which one leaf per triangle cannot express */
+                if (in_leaves != in_ranges) return fail(c, RT_E_INVALID, "rt_upload_scene: BVH leaves overlap (%lld triangles in ranges that hold %lld)", (long long)in_leaves, (long long)in_ranges);
+                keep.resize((size_t)cnt[(size_t)tri_thr]);
+                rtown::parallel_parts(s->n_tris, tri_thr, [&](int p, int64_t k0, int64_t k1) {
+                    int32_t *out = keep.data() + cnt[(size_t)p];
+                    for (int64_t k = k0; k < k1; k++)
+                        if (kept(k)) *out++ = (int32_t)k;
                 });
             }
-            clk.mark("leaf table, triangle subset");
-            if (!sub.empty()) {
-                rtown::Built own = rtown::build(sub.data(), (int64_t)sub.size());
-                clk.mark("filter tree build");
+            rtown::stage_tick("rt_upload_scene: leaf table, triangle subset");
+            if (!keep.empty()) {
+                rtown::Built own = rtown::build(s->tris, keep.data(), (int64_t)keep.size());
+                rtown::stage_tick("rt_upload_scene: filter tree build");
                 if (own.ok && (int64_t)own.nodes.size() < (1LL << RT_NODE_BITS)) {
-                    std::vector<rt_tri> otris(sub.size());
-                    rtown::parallel_parts((int64_t)sub.size(), sub.size() >= (1u << 16) ? host_thr : 1, [&](int, int64_t k0, int64_t k1) {
-                        for (int64_t k = k0; k < k1; k++) otris[(size_t)k] = sub[(size_t)own.order[(size_t)k]];
+                    /* the filter tree's triangle array is gathered on the device from the triangles already there */
+                    rtown::raw_vector<int32_t> pos(keep.size());
+                    rtown::parallel_parts((int64_t)keep.size(), keep.size() >= (1u << 16) ? host_thr : 1, [&](int, int64_t k0, int64_t k1) {
+                        for (int64_t k = k0; k < k1; k++) pos[(size_t)k] = keep[(size_t)own.order[(size_t)k]];
                     });
+                    void *d_pos = nullptr, *d_own = nullptr;
+                    if (hipMalloc(&d_own, pos.size() * sizeof(rt_tri)) != hipSuccess) return fail(c, RT_E_NOMEM, "hipMalloc of %zu bytes failed", pos.size() * sizeof(rt_tri));
+                    c->scene_allocs.push_back(d_own);
+                    c->scene_bytes += pos.size() * sizeof(rt_tri);
+                    if (hipMalloc(&d_pos, pos.size() * sizeof(int32_t)) != hipSuccess) return fail(c, RT_E_NOMEM, "hipMalloc of %zu bytes failed", pos.size() * sizeof(int32_t));
+                    hipError_t e = hipMemcpyAsync(d_pos, pos.data(), pos.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
+                    if (e == hipSuccess) {
+                        const uint32_t n = (uint32_t)pos.size();
+                        rt_gather_tris_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(d.tris, (const int32_t *)d_pos, n, (rt_tri *)d_own);
+                        e = hipGetLastError();
+                    }
+                    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                    (void)hipFree(d_pos);
+                    HIPCHK(c, e);
+                    d.own_tris = (const rt_tri *)d_own;
                     if ((rc = upload_array(c, own.wide.data(), own.wide.size(), &d.own_rec4))) return rc;
-                    if ((rc = upload_array(c, otris.data(), otris.size(), &d.own_tris))) return rc;
                     if ((rc = upload_array(c, tri_leaf.data(), tri_leaf.size(), &d.tri_leaf))) return rc;
                     if ((rc = upload_array(c, leaf_box.data(), leaf_box.size(), &d.leaf_box32))) return rc;
                     d.n_own_nodes = (uint32_t)own.wide.size();
-                    d.n_own_tris = (uint32_t)otris.size();
+                    d.n_own_tris = (uint32_t)pos.size();
                     own_depth = 3 * own.wide_depth + 2; /* stack entries the depth-first tail of a wide traversal can add */
                     HIPCHK(c, hipStreamSynchronize(c->stream));
                 }
             }
         }
-        clk.mark("filter tree reorder + copies");
+        rtown::stage_tick("rt_upload_scene: filter tree reorder + copies");
         if ((rc = upload_array(c, rec32.data(), rec32.size(), &d.rec32))) return rc;
         d.n_nodes_total = (uint32_t)rec32.size();
         if ((rc = upload_array(c, halves.data(), halves.size(), &d.halves))) return rc;
-        if ((rc = upload_array(c, s->tris, (size_t)s->n_tris, &d.tris))) return rc;
         HIPCHK(c, hipStreamSynchronize(c->stream)); /* the staging vectors go out of scope */
     }
     if ((rc = upload_array(c, s->attrs, (size_t)s->n_tris, &d.attrs))) return rc;
@@ -826,7 +854,7 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
         c->waves_per_cu = per_cu < by_regs ? per_cu : by_regs;
     }
     c->have_scene = true;
-    clk.mark("remaining copies, occupancy");
+    rtown::stage_tick("rt_upload_scene: remaining copies, occupancy");
     return RT_OK;
 }
 

@@ -4,6 +4,7 @@
  * Reference behaviour followed per function (file:line = /root/reference/raytracer.cpp).
  */
 #include "rt_host.hpp"
+#include "rt_threads.hpp"
 
 #include <math.h>
 #include <stddef.h>
@@ -394,17 +395,10 @@ size_t FlatScene::bytes() const {
            tris.size() * (sizeof(rt_tri) + sizeof(rt_tri_attr)) + tex.size() * sizeof(rt_texture) + texels.size() + sizeof lut;
 }
 
-namespace {
-int flatten_threads() { /* OMP_NUM_THREADS when set (a scheduler's share of the machine), else the hardware's count, at most 64 */
-    int t = 0;
-    if (const char *e = getenv("OMP_NUM_THREADS")) t = atoi(e);
-    if (t <= 0) t = (int)std::thread::hardware_concurrency();
-    return t <= 0 ? 1 : (t > 64 ? 64 : t);
-}
-} // namespace
-
 void flatten(const Scene &scene, FlatScene &out) {
     out = FlatScene();
+    rtown::stage_tick(nullptr);
+    rtown::PoolScope pool(rtown::host_threads()); /* the caller's, when it has one already */
     {
         size_t nt = 0, ntexel = 0;
         for (const Object *o : scene.objects)
@@ -473,7 +467,7 @@ void flatten(const Scene &scene, FlatScene &out) {
         out.tris.resize(base + visit.size());
         out.attrs.resize(base + visit.size());
         /* the triangles are independent: large meshes are filled by several threads; the first error of each is kept */
-        const int threads = visit.size() >= (1u << 16) ? flatten_threads() : 1;
+        const int threads = visit.size() >= (1u << 12) ? rtown::host_threads() : 1;
         std::vector<const char *> err((size_t)threads, nullptr);
         auto fill = [&](int part, size_t vk0, size_t vk1) {
             for (size_t vk = vk0; vk < vk1; vk++) {
@@ -505,13 +499,7 @@ void flatten(const Scene &scene, FlatScene &out) {
                 }
             }
         };
-        {
-            std::vector<std::thread> th;
-            const size_t n = visit.size();
-            for (int p = 1; p < threads; p++) th.emplace_back(fill, p, n * (size_t)p / (size_t)threads, n * (size_t)(p + 1) / (size_t)threads);
-            fill(0, 0, n / (size_t)threads);
-            for (auto &t : th) t.join();
-        }
+        rtown::parallel_parts((int64_t)visit.size(), threads, [&](int part, int64_t vk0, int64_t vk1) { fill(part, (size_t)vk0, (size_t)vk1); });
         for (const char *e : err)
             if (e) throw std::runtime_error(e);
         /* nodes: one record per inner Noeud holding both child boxes; children get larger indices */
@@ -547,6 +535,7 @@ void flatten(const Scene &scene, FlatScene &out) {
         }
         out.meshes.push_back(rm);
     }
+    rtown::stage_tick("flatten");
 }
 
 /* ---- Renderer -------------------------------------------------------------------------------- */
@@ -561,6 +550,7 @@ Renderer::~Renderer() { rt_destroy(ctx_); }
 void Renderer::setScene(const Scene &scene) {
     if (scene.objects.empty() || !dynamic_cast<const Sphere *>(scene.objects[0]))
         throw std::runtime_error("setScene: objects[0] must be the light Sphere (raytracer.cpp:970)");
+    rtown::PoolScope pool(rtown::host_threads()); /* one set of worker threads for flattening and the upload's builds */
     FlatScene fs;
     flatten(scene, fs);
     rt_scene_desc d = fs.desc();
@@ -869,6 +859,7 @@ int rth_scene_add_mesh(rth_scene *s, rth_mesh *m) {
 int rth_scene_upload(rth_scene *s, rt_ctx *ctx, int64_t *flat_bytes) {
     try {
         rt::FlatScene fs;
+        rtown::PoolScope pool(rtown::host_threads()); /* shared by flattening and the upload's builds */
         rt::flatten(s->s, fs);
         if (flat_bytes) *flat_bytes = (int64_t)fs.bytes();
         rt_scene_desc d = fs.desc();

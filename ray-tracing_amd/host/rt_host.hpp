@@ -15,8 +15,11 @@
 #pragma once
 #include <stdint.h>
 
+#include <memory>
+#include <new>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "rt_amd.h"
@@ -155,12 +158,23 @@ struct RenderParams {
 };
 
 /* scene flattened into the arrays rt_upload_scene takes */
+/* allocator whose vectors leave plain structs unwritten on resize(): flatten() sizes the triangle arrays and fills them
+ * with several threads, and zeroing them first would take one thread as long as the fill */
+template <typename T>
+struct UninitAlloc : std::allocator<T> {
+    template <typename U> struct rebind { using other = UninitAlloc<U>; };
+    UninitAlloc() = default;
+    template <typename U> UninitAlloc(const UninitAlloc<U> &) {}
+    template <typename U> void construct(U *p) { ::new ((void *)p) U; }
+    template <typename U, typename... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
+};
+
 struct FlatScene {
     std::vector<rt_sphere> spheres;
     std::vector<rt_mesh> meshes;
     std::vector<rt_bvh_node> nodes;
-    std::vector<rt_tri> tris;
-    std::vector<rt_tri_attr> attrs;
+    std::vector<rt_tri, UninitAlloc<rt_tri>> tris;
+    std::vector<rt_tri_attr, UninitAlloc<rt_tri_attr>> attrs;
     std::vector<rt_texture> tex;
     std::vector<uint8_t> texels;
     double lut[256];

@@ -1,5 +1,5 @@
 # rocprofv3 evidence for one bench configuration: kernel trace + stats, then counter passes (a run of its own each).
-#   tools/prof_round2.sh cfg4 64 1024      -> gpurun_out/prof_cfg4/{kernel_stats.csv, pmc1.json, mem1.json, mem2.json, mem3.json, bench.json}
+#   tools/prof_config.sh cfg4 64 1024      -> gpurun_out/prof_cfg4/{kernel_stats.csv, pmc1.json, mem1.json, mem2.json, mem3.json, bench.json}
 set -e
 cfg=$1; spp=$2; size=$3
 cd /tmp && export TMPDIR=/tmp

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One line per configuration from the committed round-2 profile summaries (profiles/r2_<cfg>_*)."""
+"""One line per configuration from the committed profile summaries profiles/r2_<cfg>_*."""
 import json, os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for cfg in ("cfg1", "cfg2", "cfg3", "cfg4", "cfg5"):
