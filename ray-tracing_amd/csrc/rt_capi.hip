@@ -1228,6 +1228,23 @@ int rt_debug_scene_sizes(rt_ctx *c, uint64_t *out4) {
     return RT_OK;
 }
 
+/* not part of the public header: FNV-1a hash over the filter tree's records and its triangle array as they sit on the device
+ * (tests/ only: the tree must not depend on the number of host threads that built it); 0 when the scene has no filter tree */
+int rt_debug_filter_tree_hash(rt_ctx *c, uint64_t *out) {
+    if (!c || !out || !c->have_scene) return RT_E_INVALID;
+    *out = 0;
+    if (!c->sc.own_rec4) return RT_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<unsigned char> buf((size_t)c->sc.n_own_nodes * sizeof(NodeRec4) + (size_t)c->sc.n_own_tris * sizeof(rt_tri));
+    HIPCHK(c, hipMemcpyAsync(buf.data(), c->sc.own_rec4, (size_t)c->sc.n_own_nodes * sizeof(NodeRec4), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(buf.data() + (size_t)c->sc.n_own_nodes * sizeof(NodeRec4), c->sc.own_tris, (size_t)c->sc.n_own_tris * sizeof(rt_tri), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint64_t h = 1469598103934665603ull;
+    for (unsigned char b : buf) { h ^= b; h *= 1099511628211ull; }
+    *out = h;
+    return RT_OK;
+}
+
 /* not part of the public header: rt_intersect_rays with / without distance pruning (tests/ only) */
 int rt_debug_probe_prune(rt_ctx *c, int on) {
     if (!c) return RT_E_INVALID;

@@ -94,7 +94,10 @@ static const int kBins = RT_OWN_BINS;
 static const int kLeaf = RT_OWN_LEAF; /* at most 8: the leaf count has three bits in a child code */
 static const int kSahDepth = 40; /* below this depth ranges are halved by count, which bounds the depth */
 static const double kCoordMax = 1e37; /* larger coordinates (or non-finite ones) get no tree: twice a centre must fit a float */
-static const int64_t kSubtree = 1 << 16; /* ranges up to this size are built by one thread, on a copy of their boxes */
+#ifndef RT_OWN_SUBTREE
+#define RT_OWN_SUBTREE (1 << 16)
+#endif
+static const int64_t kSubtree = RT_OWN_SUBTREE; /* ranges up to this size are built by one thread, on a copy of their boxes */
 
 /* Builds the binary tree over the primitives idx[0 .. n) of `fb`; `tmp` is scratch of the same length as idx. A leaf of
  * a record names positions pos0 + k of idx. */

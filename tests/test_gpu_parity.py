@@ -414,3 +414,17 @@ def test_cpp_host_program_matches_python_path(gpu, rta, scenes, tmp_path):
     assert np.array_equal(gpu.resolve(W, W, spp), img)
     r = subprocess.run([exe, out, "32", "1", "/nonexistent.obj"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "cannot open" in r.stderr
+
+
+def test_filter_tree_independent_of_host_threads(gpu, rta, scenes, monkeypatch):
+    """The set-up's builds run on OMP_NUM_THREADS host threads; the tree that reaches the device is the same for any count."""
+    import ctypes as C
+    s = scenes.battle(W=32)[0]  # 698 316 triangles: the top of the tree is cut by all threads together, the rest as subtrees
+    hashes = []
+    for threads in ("1", "3", "16"):
+        monkeypatch.setenv("OMP_NUM_THREADS", threads)
+        gpu.upload(s)
+        h = C.c_uint64()
+        assert rta.lib.rt_debug_filter_tree_hash(gpu._h, C.byref(h)) == 0
+        hashes.append(h.value)
+    assert hashes[0] != 0 and hashes[0] == hashes[1] == hashes[2], hashes

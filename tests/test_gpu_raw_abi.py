@@ -102,6 +102,7 @@ def test_hand_built_scene_and_its_corruptions(gpu, rta):
     broken(set_field("nodes", "L", 3))               # leaf range beyond the triangles
     broken(set_field("nodes", "nL", -1))
     broken(set_field("nodes", "nR", 0))              # inner child that does not point forward
+    broken(set_field("nodes", "R", 1))               # the two leaves share triangle 1
     broken(set_field("meshes", "n_tris", 3))         # does not cover the triangle array
     broken(set_field("meshes", "root", 7))
     broken(set_field("meshes", "max_depth", 61))
