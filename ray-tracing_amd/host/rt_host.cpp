@@ -450,9 +450,23 @@ void flatten(const Scene &scene, FlatScene &out) {
         std::vector<int> visit; /* visit[new position - first_tri] = position in m->indices */
         visit.reserve(m->indices.size());
         {
-            std::vector<int> leaves;
-            for (size_t k = 0; k < m->bvh.size(); k++) if (m->bvh[k].fg < 0) leaves.push_back((int)k);
-            std::sort(leaves.begin(), leaves.end(), [&](int x, int y) { return m->bvh[x].debut > m->bvh[y].debut; });
+            /* the leaves by descending `debut`: their ranges tile [0, n), so a table over debut orders them in one pass
+             * (two leaves with one debut - an empty range - fall back to sorting) */
+            std::vector<int> leaves, leaf_at(m->indices.size() + 1, -1);
+            bool tiled = true;
+            for (size_t k = 0; k < m->bvh.size(); k++)
+                if (m->bvh[k].fg < 0) {
+                    const int d = m->bvh[k].debut;
+                    if (d < 0 || (size_t)d > m->indices.size() || leaf_at[(size_t)d] >= 0) { tiled = false; break; }
+                    leaf_at[(size_t)d] = (int)k;
+                }
+            if (tiled) {
+                for (size_t d = leaf_at.size(); d-- > 0;)
+                    if (leaf_at[d] >= 0) leaves.push_back(leaf_at[d]);
+            } else {
+                for (size_t k = 0; k < m->bvh.size(); k++) if (m->bvh[k].fg < 0) leaves.push_back((int)k);
+                std::sort(leaves.begin(), leaves.end(), [&](int x, int y) { return m->bvh[x].debut > m->bvh[y].debut; });
+            }
             for (size_t q = 0; q < leaves.size(); q++) {
                 const BVHNode &lf = m->bvh[(size_t)leaves[q]];
                 leaf_new_first[(size_t)lf.debut] = rm.first_tri + (int)visit.size();
@@ -460,6 +474,7 @@ void flatten(const Scene &scene, FlatScene &out) {
             }
         }
         if (visit.size() != m->indices.size()) throw std::runtime_error("flatten: BVH leaves do not cover the triangles");
+        rtown::stage_tick("  flatten: visit order");
         /* A, e1 = B - A, e2 = C - A (:673-677) and the gathered attributes */
         const int nn = (int)m->normals.size(), nuv = (int)m->uvs.size();
         const int32_t mesh_index = (int32_t)out.meshes.size();
@@ -502,6 +517,7 @@ void flatten(const Scene &scene, FlatScene &out) {
         rtown::parallel_parts((int64_t)visit.size(), threads, [&](int part, int64_t vk0, int64_t vk1) { fill(part, (size_t)vk0, (size_t)vk1); });
         for (const char *e : err)
             if (e) throw std::runtime_error(e);
+        rtown::stage_tick("  flatten: triangles");
         /* nodes: one record per inner Noeud holding both child boxes; children get larger indices */
         if (m->bvh[0].fg < 0) {
             rm.root = leaf_new_first[(size_t)m->bvh[0].debut];
@@ -512,16 +528,18 @@ void flatten(const Scene &scene, FlatScene &out) {
             for (size_t k = 0; k < m->bvh.size(); k++) /* bvh is in creation order: parents before children */
                 if (m->bvh[k].fg >= 0) rec_of[k] = next++;
             out.nodes.resize((size_t)next);
-            for (size_t k = 0; k < m->bvh.size(); k++) {
-                const BVHNode &n = m->bvh[k];
-                if (n.fg < 0) continue;
-                rt_bvh_node &r = out.nodes[(size_t)rec_of[k]];
-                memset(&r, 0, sizeof r);
-                const BVHNode &a = m->bvh[n.fg], &b = m->bvh[n.fd];
-                for (int q = 0; q < 6; q++) { r.boxL[q] = a.box[q]; r.boxR[q] = b.box[q]; }
-                if (a.fg >= 0) { r.L = rec_of[n.fg]; r.nL = 0; } else { r.L = leaf_new_first[(size_t)a.debut]; r.nL = a.fin - a.debut; }
-                if (b.fg >= 0) { r.R = rec_of[n.fd]; r.nR = 0; } else { r.R = leaf_new_first[(size_t)b.debut]; r.nR = b.fin - b.debut; }
-            }
+            rtown::parallel_parts((int64_t)m->bvh.size(), m->bvh.size() >= (1u << 14) ? rtown::host_threads() : 1, [&](int, int64_t k0, int64_t k1) {
+                for (int64_t k = k0; k < k1; k++) {
+                    const BVHNode &n = m->bvh[(size_t)k];
+                    if (n.fg < 0) continue;
+                    rt_bvh_node &r = out.nodes[(size_t)rec_of[(size_t)k]];
+                    memset(&r, 0, sizeof r);
+                    const BVHNode &a = m->bvh[n.fg], &b = m->bvh[n.fd];
+                    for (int q = 0; q < 6; q++) { r.boxL[q] = a.box[q]; r.boxR[q] = b.box[q]; }
+                    if (a.fg >= 0) { r.L = rec_of[n.fg]; r.nL = 0; } else { r.L = leaf_new_first[(size_t)a.debut]; r.nL = a.fin - a.debut; }
+                    if (b.fg >= 0) { r.R = rec_of[n.fd]; r.nR = 0; } else { r.R = leaf_new_first[(size_t)b.debut]; r.nR = b.fin - b.debut; }
+                }
+            });
             rm.root = rec_of[0];
             rm.root_count = 0;
         }
@@ -534,8 +552,8 @@ void flatten(const Scene &scene, FlatScene &out) {
             out.texels.insert(out.texels.end(), m->textures[k].begin(), m->textures[k].end());
         }
         out.meshes.push_back(rm);
+        rtown::stage_tick("  flatten: records, textures");
     }
-    rtown::stage_tick("flatten");
 }
 
 /* ---- Renderer -------------------------------------------------------------------------------- */

@@ -172,7 +172,7 @@ struct UninitAlloc : std::allocator<T> {
 struct FlatScene {
     std::vector<rt_sphere> spheres;
     std::vector<rt_mesh> meshes;
-    std::vector<rt_bvh_node> nodes;
+    std::vector<rt_bvh_node, UninitAlloc<rt_bvh_node>> nodes;
     std::vector<rt_tri, UninitAlloc<rt_tri>> tris;
     std::vector<rt_tri_attr, UninitAlloc<rt_tri_attr>> attrs;
     std::vector<rt_texture> tex;
