@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Random scenes against the CPU checker: tools/fuzz_parity.py [first_seed [n_scenes]]
+"""Random scenes against the CPU checker: python tests/fuzz_parity.py [first_seed [n_scenes]]
 
 Every scene is a random mix of what the hand-written tests cover one at a time: few or many spheres (the list staged in
 LDS, or the sphere tree), equal and nested spheres, zero to four meshes of 12 to 24 300 triangles, a mesh repeated in place

@@ -1,4 +1,4 @@
-"""Random scene mixes (tools/fuzz_parity.py) against the oracle: equal and nested spheres, sphere lists on either side of
+"""Random scene mixes (tests/fuzz_parity.py, which also runs on its own over any range of seeds) against the oracle: equal and nested spheres, sphere lists on either side of
 the LDS limit, meshes repeated in place, triangles repeated inside a mesh, meshes in coordinate planes, all materials, rays
 aimed at vertices and edge midpoints. Hit identity and t bit for bit with and without pruning; every sample within 1e-9
 and on the same path."""
@@ -9,7 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-_spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+_spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_parity.py"))
 fuzz = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(fuzz)
 
