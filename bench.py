@@ -124,15 +124,34 @@ def main():
     cpu_spp = args.cpu_spp or cpu_spp
 
     # ---- set-up: what precedes any render (the reference's own 12 s @ 1 spp, README.md:129, includes it) ----
+    # The context (HIP runtime, code object, stream, scratch) does not depend on the scene: it is created by a second
+    # thread while this one builds the scene, as a host program would do it.
+    import threading
+    made = {}
+
+    def make_context():
+        ta = time.perf_counter()
+        try:
+            made["r"] = rta.Renderer(local_rank)
+        except Exception as e:  # reported by the main thread
+            made["error"] = e
+        made["s"] = time.perf_counter() - ta
+
     t0 = time.perf_counter()
+    th = threading.Thread(target=make_context)
+    th.start()
     out = getattr(scenes, builder)(W=W, **kw)   # scene construction: procedural meshes, transforms, buildBVH per mesh
     scene, cam, flags = out[0], out[1], out[2]
     t1 = time.perf_counter()
-    r = rta.Renderer(local_rank)
+    th.join()
+    if "error" in made:
+        raise made["error"]
+    r = made["r"]
     t2 = time.perf_counter()
     r.upload(scene)                              # flatten + derived trees + copy to HBM
     t3 = time.perf_counter()
-    setup = {"scene_build_s": round(t1 - t0, 3), "context_s": round(t2 - t1, 3), "upload_s": round(t3 - t2, 3), "total_s": round(t3 - t0, 3)}
+    setup = {"scene_build_s": round(t1 - t0, 3), "context_s": round(made["s"], 3), "context_overlapped": True, "upload_s": round(t3 - t2, 3),
+             "total_s": round(t3 - t0, 3)}
     info = scene.flat_info()
 
     accum = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
@@ -210,7 +229,7 @@ def main():
             png_s = round(time.perf_counter() - tp, 3)
         tti = {"spp": spp_image, "render_reduce_resolve_s": round(tb, 4), "setup_s": round(su, 3), "total_s": round(tb + su, 3),
                "Mpaths_per_s": round(float(W) * H * spp_image / tb / 1e6, 2), "png_write_s": png_s,
-               "note": "set-up = scene construction (procedural stand-in meshes, transforms, buildBVH per mesh) + context + rt_upload_scene, max over ranks; "
+               "note": "set-up = scene construction (procedural stand-in meshes, transforms, buildBVH per mesh) with the context created beside it, then flatten + rt_upload_scene, max over ranks; "
                        "render = %d samples per pixel split over %d rank(s), reduce to rank 0, tone map, image in host memory" % (spp_image, world)}
 
     if rank == 0:
