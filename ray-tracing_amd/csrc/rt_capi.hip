@@ -542,8 +542,22 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
         if (m.n_tris < 0 || m.first_tri < 0 || (int64_t)m.first_tri + m.n_tris > s->n_tris) return fail(c, RT_E_INVALID, "mesh %d: triangle range outside the triangle array", mi);
         if (m.n_tex < 0 || m.first_tex < 0 || m.first_tex + m.n_tex > s->n_tex) return fail(c, RT_E_INVALID, "mesh %d: texture range outside the texture array", mi);
         if (m.max_depth < 0 || m.max_depth > RT_MAX_DEPTH) return fail(c, RT_E_INVALID, "mesh %d: BVH depth %d outside [0,%d]", mi, m.max_depth, RT_MAX_DEPTH);
-        for (int32_t k = m.first_tri; k < m.first_tri + m.n_tris; k++)
-            if (s->tris[k].mesh != mi) return fail(c, RT_E_INVALID, "mesh %d: triangle %d carries mesh index %d", mi, k, s->tris[k].mesh);
+        {
+            /* per triangle: its mesh index and, on a textured mesh, its texture group (the reference indexes
+             * textures[group] unchecked, raytracer.cpp:700-701); shared out over the threads, the lowest offender is reported */
+            const int thr = m.n_tris >= (1 << 16) ? rtown::host_threads() : 1;
+            std::vector<int64_t> bad_mesh((size_t)thr, -1), bad_group((size_t)thr, -1);
+            rtown::parallel_parts(m.n_tris, thr, [&](int part, int64_t k0, int64_t k1) {
+                for (int64_t k = m.first_tri + k0; k < m.first_tri + k1; k++) {
+                    if (s->tris[k].mesh != mi && bad_mesh[(size_t)part] < 0) bad_mesh[(size_t)part] = k;
+                    if (m.n_tex > 0 && (s->attrs[k].group < 0 || s->attrs[k].group >= m.n_tex) && bad_group[(size_t)part] < 0) bad_group[(size_t)part] = k;
+                }
+            });
+            for (int64_t k : bad_mesh)
+                if (k >= 0) return fail(c, RT_E_INVALID, "mesh %d: triangle %lld carries mesh index %d", mi, (long long)k, s->tris[k].mesh);
+            for (int64_t k : bad_group)
+                if (k >= 0) return fail(c, RT_E_INVALID, "mesh %d: triangle %lld has texture group %d but the mesh has %d textures", mi, (long long)k, s->attrs[k].group, m.n_tex);
+        }
         if (m.root_count < 0) return fail(c, RT_E_INVALID, "mesh %d: negative root_count", mi);
         if (m.root_count > 0) {
             if (m.root < m.first_tri || (int64_t)m.root + m.root_count > (int64_t)m.first_tri + m.n_tris) return fail(c, RT_E_INVALID, "mesh %d: root leaf outside its triangles", mi);
@@ -552,31 +566,40 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
         } else if (m.root < 0 || m.root >= s->n_nodes) {
             return fail(c, RT_E_INVALID, "mesh %d: root node outside the node array", mi);
         }
-        if (m.n_tex > 0)
-            for (int32_t k = m.first_tri; k < m.first_tri + m.n_tris; k++) {
-                int g = s->attrs[k].group;
-                /* the reference indexes textures[group] unchecked (raytracer.cpp:700-701) */
-                if (g < 0 || g >= m.n_tex) return fail(c, RT_E_INVALID, "mesh %d: triangle %d has texture group %d but the mesh has %d textures", mi, k, g, m.n_tex);
-            }
     }
     /* largest |coordinate| of any box, per axis: scales the tolerance of the fast box test (rt_device.hip.h) */
     double bmax[3] = {0, 0, 0};
-    auto widen = [&bmax](const double *box) {
+    auto widen_into = [](double *bm, const double *box) {
         for (int k = 0; k < 6; k++) {
             const double a = fabs(box[k]);
-            if (!(a <= bmax[k % 3])) bmax[k % 3] = std::isfinite(a) && std::isfinite(bmax[k % 3]) ? a : HUGE_VAL;
+            if (!(a <= bm[k % 3])) bm[k % 3] = std::isfinite(a) && std::isfinite(bm[k % 3]) ? a : HUGE_VAL;
         }
     };
+    auto widen = [&](const double *box) { widen_into(bmax, box); };
     for (int mi = 0; mi < s->n_meshes; mi++) widen(s->meshes[mi].root_box);
-    for (int64_t k = 0; k < s->n_nodes; k++) {
-        const rt_bvh_node &nd = s->nodes[k];
-        widen(nd.boxL);
-        widen(nd.boxR);
-        const int32_t idx[2] = {nd.L, nd.R}, cnt[2] = {nd.nL, nd.nR};
-        for (int q = 0; q < 2; q++) {
-            if (cnt[q] < 0) return fail(c, RT_E_INVALID, "node %lld: negative leaf count", (long long)k);
-            if (cnt[q] == 0 ? (idx[q] <= k || idx[q] >= s->n_nodes) : (idx[q] < 0 || (int64_t)idx[q] + cnt[q] > s->n_tris))
-                return fail(c, RT_E_INVALID, "node %lld: child %d out of range (inner children must have a larger index)", (long long)k, q);
+    {
+        const int thr = s->n_nodes >= (1 << 16) ? rtown::host_threads() : 1;
+        struct NodeCheck { double bm[3] = {0, 0, 0}; int64_t bad = -1; int what = 0; };
+        std::vector<NodeCheck> part((size_t)thr);
+        rtown::parallel_parts(s->n_nodes, thr, [&](int p, int64_t k0, int64_t k1) {
+            NodeCheck &P = part[(size_t)p];
+            for (int64_t k = k0; k < k1; k++) {
+                const rt_bvh_node &nd = s->nodes[k];
+                widen_into(P.bm, nd.boxL);
+                widen_into(P.bm, nd.boxR);
+                if (P.bad >= 0) continue;
+                const int32_t idx[2] = {nd.L, nd.R}, cnt[2] = {nd.nL, nd.nR};
+                for (int q = 0; q < 2 && P.bad < 0; q++) {
+                    if (cnt[q] < 0) { P.bad = k; P.what = -1; }
+                    else if (cnt[q] == 0 ? (idx[q] <= k || idx[q] >= s->n_nodes) : (idx[q] < 0 || (int64_t)idx[q] + cnt[q] > s->n_tris)) { P.bad = k; P.what = 1 + q; }
+                }
+            }
+        });
+        for (const NodeCheck &P : part) {
+            if (P.bad >= 0 && P.what < 0) return fail(c, RT_E_INVALID, "node %lld: negative leaf count", (long long)P.bad);
+            if (P.bad >= 0) return fail(c, RT_E_INVALID, "node %lld: child %d out of range (inner children must have a larger index)", (long long)P.bad, P.what - 1);
+            for (int a = 0; a < 3; a++)
+                if (!(P.bm[a] <= bmax[a])) bmax[a] = std::isfinite(P.bm[a]) && std::isfinite(bmax[a]) ? P.bm[a] : HUGE_VAL;
         }
     }
     for (int k = 0; k < s->n_tex; k++) {

@@ -549,7 +549,11 @@ void flatten(const Scene &scene, FlatScene &out) {
             tx.W = m->Wtex[k];
             tx.H = m->Htex[k];
             out.tex.push_back(tx);
-            out.texels.insert(out.texels.end(), m->textures[k].begin(), m->textures[k].end());
+            const std::vector<uint8_t> &src = m->textures[k];
+            out.texels.resize((size_t)tx.offset + src.size()); /* reserved above: no reallocation */
+            rtown::parallel_parts((int64_t)src.size(), src.size() >= (1u << 20) ? rtown::host_threads() : 1, [&](int, int64_t b0, int64_t b1) {
+                memcpy(out.texels.data() + tx.offset + b0, src.data() + b0, (size_t)(b1 - b0));
+            });
         }
         out.meshes.push_back(rm);
         rtown::stage_tick("  flatten: records, textures");

@@ -176,7 +176,7 @@ struct FlatScene {
     std::vector<rt_tri, UninitAlloc<rt_tri>> tris;
     std::vector<rt_tri_attr, UninitAlloc<rt_tri_attr>> attrs;
     std::vector<rt_texture> tex;
-    std::vector<uint8_t> texels;
+    std::vector<uint8_t, UninitAlloc<uint8_t>> texels;
     double lut[256];
     double I;
     double L[3];
