@@ -72,6 +72,13 @@ namespace rtd {
 #define RT_LOW_MASK ((1u << RT_NODE_BITS) - 1u)
 #define RT_MAX_DEPTH 60
 #define RT_STEP_LIMIT (1u << 24)  /* pool steps of one query after which it is given up (and reported) */
+#ifndef RT_OWN_LEAF
+#define RT_OWN_LEAF 4             /* primitives per leaf of the filter trees, at most 8 (three bits in a child code) */
+#endif
+#ifndef RT_SPH_LEAF
+#define RT_SPH_LEAF 1             /* spheres per leaf of the tree over a long sphere list, at most 8; 1: a leaf item is one test, and the
+                                     leaf step needs no prefix sum to spread items over lanes (cfg5: +5.6 % against 4) */
+#endif
 #ifndef RT_EXT_LEAF
 #define RT_EXT_LEAF 4             /* reference leaves with more triangles than this get extension records down to this size */
 #endif
@@ -804,28 +811,40 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
                     cntl = (int)(it.y & RT_LOW_MASK);
                     if (w->leaf_t[n_leaves - 1 - lane] > w->thrf[it.y >> RT_NODE_BITS]) cntl = 0;
                 }
+                bool have;
+                uint32_t tri;
+                int rl, take;
+                if ((SPHP ? RT_SPH_LEAF : RT_OWN_LEAF) == 1 && own) {
+                    /* every leaf of the filter trees is one primitive: an item is a slot, nothing to spread out */
+                    have = cntl > 0;
+                    tri = it.x;
+                    rl = (int)(it.y >> RT_NODE_BITS);
+                    take = m;
+                    n_leaves -= m;
+                } else {
                 const int incl = wave_scan_add(cntl);
                 const int excl = incl - cntl;
                 const int total = __builtin_amdgcn_readlane(incl, 63);
-                const int take = total < RT_WAVE ? total : RT_WAVE;
+                take = total < RT_WAVE ? total : RT_WAVE;
                 w->mark[lane] = -1;
                 wave_sync();
                 if (cntl > 0 && excl < RT_WAVE) w->mark[excl] = lane;
                 w->ex[lane] = excl;
                 wave_sync();
                 const int j = wave_scan_max(w->mark[lane]);
-                const bool have = lane < take; /* then j >= 0: slot 0 carries the marker of the first non-empty item */
+                have = lane < take; /* then j >= 0: slot 0 carries the marker of the first non-empty item */
                 uint2 itj = make_uint2(0u, 0u);
                 int exj = 0;
                 if (have) { itj = w->leaf[n_leaves - 1 - j]; exj = w->ex[j]; }
-                const uint32_t tri = itj.x + (uint32_t)(lane - exj);
-                const int rl = (int)(itj.y >> RT_NODE_BITS);
+                tri = itj.x + (uint32_t)(lane - exj);
+                rl = (int)(itj.y >> RT_NODE_BITS);
                 wave_sync();
                 if (lane < m && excl < RT_WAVE && incl > RT_WAVE) { /* the item cut by the last slot */
                     const uint32_t used = (uint32_t)(RT_WAVE - excl);
                     w->leaf[n_leaves - 1 - lane] = make_uint2(it.x + used, ((uint32_t)cntl - used) | (it.y & ~RT_LOW_MASK));
                 }
                 n_leaves = uni(n_leaves - __popcll(__ballot(lane < m && incl <= RT_WAVE)));
+                }
                 const int k = take;
                 bool acc = false;
                 double beta, gamma, lt = 0;

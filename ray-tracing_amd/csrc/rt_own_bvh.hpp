@@ -88,10 +88,8 @@ static inline FBox box_to_float(const Bounds &b) {
 #define RT_OWN_BINS 16
 #endif
 static const int kBins = RT_OWN_BINS;
-#ifndef RT_OWN_LEAF
-#define RT_OWN_LEAF 4
-#endif
-static const int kLeaf = RT_OWN_LEAF; /* at most 8: the leaf count has three bits in a child code */
+static const int kLeaf = RT_OWN_LEAF;    /* triangles per leaf; at most 8: the leaf count has three bits in a child code */
+static const int kSphLeaf = RT_SPH_LEAF; /* spheres per leaf of a sphere tree */
 static const int kSahDepth = 40; /* below this depth ranges are halved by count, which bounds the depth */
 static const double kCoordMax = 1e37; /* larger coordinates (or non-finite ones) get no tree: twice a centre must fit a float */
 #ifndef RT_OWN_SUBTREE
@@ -105,6 +103,7 @@ struct Builder {
     const FBox *fb;
     int32_t *idx, *tmp;
     int64_t pos0;
+    int leaf; /* ranges of at most this many primitives are leaves */
 
     struct Job {
         int64_t node; /* record that holds this range as child `side`, or -1 for the root range */
@@ -261,13 +260,13 @@ struct Builder {
                 if (jb.side == 0) { pr.L = (int32_t)id; pr.nL = 0; } else { pr.R = (int32_t)id; pr.nR = 0; }
             }
             if (jb.depth > max_depth) max_depth = jb.depth;
-            if (nl > kLeaf) jobs.push_back(Job{id, 0, jb.first, nl, jb.depth + 1});
-            if (nr > kLeaf) jobs.push_back(Job{id, 1, jb.first + nl, nr, jb.depth + 1});
+            if (nl > leaf) jobs.push_back(Job{id, 0, jb.first, nl, jb.depth + 1});
+            if (nr > leaf) jobs.push_back(Job{id, 1, jb.first + nl, nr, jb.depth + 1});
         }
     }
 };
 
-inline Built build_boxes(const raw_vector<FBox> &fb);
+inline Built build_boxes(const raw_vector<FBox> &fb, int leaf);
 
 /* the tree over the triangles tris[keep[0 .. n)] (keep == nullptr: tris[0 .. n)); `order` counts within keep */
 inline Built build(const rt_tri *tris, const int32_t *keep, int64_t n) {
@@ -294,7 +293,7 @@ inline Built build(const rt_tri *tris, const int32_t *keep, int64_t n) {
     });
     for (char x : bad)
         if (x) return Built();
-    return build_boxes(fb);
+    return build_boxes(fb, kLeaf);
 }
 
 /* the tree over any primitives, given their (finite) boxes: the spheres of a long sphere list */
@@ -305,10 +304,10 @@ inline Built build_boxes(const std::vector<Bounds> &tb) {
             if (!(fabs(tb[k].lo[a]) < kCoordMax) || !(fabs(tb[k].hi[a]) < kCoordMax)) return Built();
         fb[k] = box_to_float(tb[k]);
     }
-    return build_boxes(fb);
+    return build_boxes(fb, kSphLeaf);
 }
 
-inline Built build_boxes(const raw_vector<FBox> &fb) {
+inline Built build_boxes(const raw_vector<FBox> &fb, int leaf) {
     Built out;
     const int64_t n = (int64_t)fb.size();
     if (n <= 0) return out;
@@ -318,8 +317,8 @@ inline Built build_boxes(const raw_vector<FBox> &fb) {
     parallel_parts(n, n >= kSubtree ? threads : 1, [&](int, int64_t b0, int64_t e0) {
         for (int64_t k = b0; k < e0; k++) idx[(size_t)k] = (int32_t)k;
     });
-    Builder B{fb.data(), idx.data(), tmp.data(), 0};
-    if (n <= kLeaf) { /* a tree needs one record: both children are leaves (the right one may be empty) */
+    Builder B{fb.data(), idx.data(), tmp.data(), 0, leaf};
+    if (n <= leaf) { /* a tree needs one record: both children are leaves (the right one may be empty) */
         rtd::NodeRec32 r;
         const int64_t nl = (n + 1) / 2;
         B.range_bounds(0, nl).store(r.boxL);
@@ -355,7 +354,7 @@ inline Built build_boxes(const raw_vector<FBox> &fb) {
             raw_vector<FBox> lb((size_t)count);
             raw_vector<int32_t> li((size_t)count), lt((size_t)count);
             for (int64_t k = 0; k < count; k++) { lb[(size_t)k] = fb[(size_t)idx[(size_t)(first + k)]]; li[(size_t)k] = (int32_t)k; }
-            Builder L{lb.data(), li.data(), lt.data(), first};
+            Builder L{lb.data(), li.data(), lt.data(), first, leaf};
             std::vector<Builder::Job> local;
             local.push_back(Builder::Job{-1, 0, 0, count, sub[t].depth});
             parts[t].nodes.reserve((size_t)count / 2);
