@@ -730,6 +730,9 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
                 if (parts[t].depth > ext_depth) ext_depth = parts[t].depth;
             }
         }
+        /* what the triangle step relies on (rt_device.hip.h: RT_LEAF_QUAD): no leaf of the traversal records is longer than RT_EXT_LEAF */
+        for (const NodeRec32 &r : rec32)
+            if (r.nL > RT_EXT_LEAF || r.nR > RT_EXT_LEAF) return fail(c, RT_E_INVALID, "rt_upload_scene: internal error, a leaf of %d triangles survived the extension records", r.nL > r.nR ? r.nL : r.nR);
         rtown::stage_tick("rt_upload_scene: extension records");
         /* The filter tree over the triangles of all meshes, and what confirms its winners: the reference leaf of every
          * triangle. A leaf whose box has no thickness along an axis is never entered by the reference (tMax > tMin cannot

@@ -65,7 +65,7 @@ namespace rtd {
 #define RT_LEAF_CAP 320           /* leaf-item stack entries */
 #endif
 #ifndef RT_LEAF_TRIGGER
-#define RT_LEAF_TRIGGER 32        /* pending leaf items that make the next pool step a triangle step */
+#define RT_LEAF_TRIGGER 16        /* pending leaf items that make the next pool step a triangle step (one full step of 64 / RT_LEAF_QUAD items) */
 #endif
 #define RT_RAY_SLOTS 128          /* rays of one query: two per lane (slot = lane, 64 + lane) */
 #define RT_NODE_BITS 25           /* record-index / leaf-count bits in a pool item (the ray slot takes the top 7) */
@@ -74,6 +74,14 @@ namespace rtd {
 #define RT_STEP_LIMIT (1u << 24)  /* pool steps of one query after which it is given up (and reported) */
 #ifndef RT_OWN_LEAF
 #define RT_OWN_LEAF 4             /* primitives per leaf of the filter trees, at most 8 (three bits in a child code) */
+#endif
+#ifndef RT_LEAF_QUAD
+#define RT_LEAF_QUAD 4            /* lanes per leaf item in a triangle step (0: as many as the item has triangles, found by a prefix sum): with
+                                     leaves of at most this many triangles, lane r of an item's group takes its r-th triangle and nothing
+                                     has to be spread out. A step then takes 16 items and costs a third of the prefix-sum form (cfg4 +1 %). */
+#endif
+#ifndef RT_SPH_TRIGGER
+#define RT_SPH_TRIGGER 64         /* the same for the sphere tree's leaf items: a step of theirs is cheap and best taken full (cfg5: +0.8 % against 32) */
 #endif
 #ifndef RT_SPH_LEAF
 #define RT_SPH_LEAF 1             /* spheres per leaf of the tree over a long sphere list, at most 8; 1: a leaf item is one test, and the
@@ -794,19 +802,23 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
         }
         /* one pool step: up to 64 items */
         {
-            const bool do_leaf = (n_leaves >= RT_LEAF_TRIGGER) || (n_nodes == 0) ||
+            const bool do_leaf = (n_leaves >= (SPHP ? RT_SPH_TRIGGER : RT_LEAF_TRIGGER)) || (n_nodes == 0) ||
                                  (n_leaves + (own ? 4 : 2) * RT_WAVE > RT_LEAF_CAP);
             if (do_leaf) {
-                /* 64 triangles per step whichever leaves they sit in: the top m <= 64 leaf items are
-                 * (first, count) ranges; a prefix sum of the counts gives every item its slots, slot s (=
-                 * lane s) finds its item through a marker + running maximum, and tests triangle
-                 * first + (s - first slot of the item). Items used up are popped, the one cut by slot 64 is
-                 * shortened in place and becomes the new top. A leaf that has fallen behind its ray's
-                 * threshold since it was pushed counts as empty. */
+                /* A triangle step tests up to 64 (ray, triangle) pairs. Three ways from leaf items to lanes:
+                 * - RT_LEAF_QUAD lanes per item when no leaf of the tree in use holds more triangles than that: lane r
+                 *   of an item's group takes its r-th triangle (the default for triangles);
+                 * - one lane per item when every leaf is one primitive (the sphere tree);
+                 * - otherwise 64 triangles whichever leaves they sit in: the top m <= 64 leaf items are (first, count)
+                 *   ranges; a prefix sum of the counts gives every item its slots, slot s (= lane s) finds its item
+                 *   through a marker + running maximum, and tests triangle first + (s - first slot of the item). Items
+                 *   used up are popped, the one cut by slot 64 is shortened in place and becomes the new top.
+                 * A leaf that has fallen behind its ray's threshold since it was pushed counts as empty. */
                 const int m = n_leaves < RT_WAVE ? n_leaves : RT_WAVE;
                 uint2 it = make_uint2(0u, 0u);
                 int cntl = 0;
-                if (lane < m) {
+                const bool quad = RT_LEAF_QUAD && !SPHP && (own ? RT_OWN_LEAF : RT_EXT_LEAF) <= RT_LEAF_QUAD;
+                if (!quad && lane < m) {
                     it = w->leaf[n_leaves - 1 - lane];
                     cntl = (int)(it.y & RT_LOW_MASK);
                     if (w->leaf_t[n_leaves - 1 - lane] > w->thrf[it.y >> RT_NODE_BITS]) cntl = 0;
@@ -814,6 +826,24 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
                 bool have;
                 uint32_t tri;
                 int rl, take;
+#if RT_LEAF_QUAD
+                if (quad) {
+                    const int mq = n_leaves < RT_WAVE / RT_LEAF_QUAD ? n_leaves : RT_WAVE / RT_LEAF_QUAD;
+                    const int iq = lane / RT_LEAF_QUAD, rq = lane % RT_LEAF_QUAD;
+                    uint2 itq = make_uint2(0u, 0u);
+                    int cq = 0;
+                    if (iq < mq) {
+                        itq = w->leaf[n_leaves - 1 - iq];
+                        cq = (int)(itq.y & RT_LOW_MASK);
+                        if (w->leaf_t[n_leaves - 1 - iq] > w->thrf[itq.y >> RT_NODE_BITS]) cq = 0;
+                    }
+                    have = rq < cq;
+                    tri = itq.x + (uint32_t)rq;
+                    rl = (int)(itq.y >> RT_NODE_BITS);
+                    take = mq * RT_LEAF_QUAD;
+                    n_leaves -= mq;
+                } else
+#endif
                 if ((SPHP ? RT_SPH_LEAF : RT_OWN_LEAF) == 1 && own) {
                     /* every leaf of the filter trees is one primitive: an item is a slot, nothing to spread out */
                     have = cntl > 0;
