@@ -988,7 +988,11 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
                 }
                 wide_children(sc, w, lane, have, rl, __uint_as_float(it.y), q0, q1, q2, q3, q4, q5, ch, n_nodes, n_leaves);
                 wave_sync();
-                if (CNT) { uint64_t t = RT_STAMP(); cnt.cyc_node += t - st0; st0 = t; cnt.node_steps++; cnt.node_lanes += (uint64_t)k; }
+                if (CNT) {
+                    uint64_t t = RT_STAMP();
+                    if (SPHP && !RT_STAMP_STEPS) { cnt.dbg[0] += t - st0; cnt.dbg[1]++; cnt.dbg[2] += (uint64_t)k; } /* the sphere tree's share of the node steps */
+                    cnt.cyc_node += t - st0; st0 = t; cnt.node_steps++; cnt.node_lanes += (uint64_t)k;
+                }
             } else {
                 /* Up to 64 BVH records per step, one per lane: both child boxes are tested (raytracer.cpp:656-665)
                  * and the children that are hit are pushed. 64 records are popped while the stack is below
