@@ -233,6 +233,15 @@ _REAL = {  # files of the reference's objects/ directory that exist there
 }
 
 
+def _host_threads():
+    """OMP_NUM_THREADS when set (a scheduler's share of the machine), else the CPU count"""
+    try:
+        t = int(os.environ.get("OMP_NUM_THREADS", "0"))
+    except ValueError:
+        t = 0
+    return t if t > 0 else (os.cpu_count() or 1)
+
+
 def battle(W=1024, tri_scale=1.0, tex_size=1024, assets_dir=None, dof_sigma=0.01):
     """cfg4: the committed scene of main(): light + 4 walls + floor + 12 meshes in the reference's
     object order with its transform chains (raytracer.cpp:1222-1355, :1401-1435). Meshes are
@@ -240,8 +249,8 @@ def battle(W=1024, tri_scale=1.0, tex_size=1024, assets_dir=None, dof_sigma=0.01
     s = Scene(I=6e9, L=(-10, 50, 40))
     s.add(Sphere(s.L, 5, (1, 1, 1)))
     _room(s)
-    meta = []
-    for k, (name, ntri, ext, zoom, ntex, albedo, ops) in enumerate(_BATTLE):
+    def make(job):
+        k, (name, ntri, ext, zoom, ntex, albedo, ops) = job
         real = None
         if assets_dir and name in _REAL and os.path.exists(os.path.join(assets_dir, _REAL[name][0])):
             real = _REAL[name]
@@ -256,8 +265,18 @@ def battle(W=1024, tri_scale=1.0, tex_size=1024, assets_dir=None, dof_sigma=0.01
         for op in ops:
             getattr(m, op[0])(*op[1:])
         m.buildBVH()
+        return m, dict(name=name, real=bool(real), **m.sizes())
+
+    # the meshes do not depend on each other: they are loaded (or generated), transformed and given their BVH by a few
+    # threads (the array work and the C++ calls run without the interpreter lock); the scene takes them in the reference's order
+    from concurrent.futures import ThreadPoolExecutor
+    workers = max(1, min(len(_BATTLE), _host_threads()))
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        made = list(pool.map(make, enumerate(_BATTLE)))
+    meta = []
+    for m, info in made:
         s.add(m)
-        meta.append(dict(name=name, real=bool(real), **m.sizes()))
+        meta.append(info)
     cam = make_camera((0, 30, 55), 60.0, -25.0, 0.0, W, dof_sigma=dof_sigma)
     return s, cam, 0, meta
 
