@@ -194,7 +194,7 @@ typedef struct rt_ctx rt_ctx;
 /* Create a context on HIP device `device` (its own stream). */
 int rt_create(int device, rt_ctx **out);
 void rt_destroy(rt_ctx *ctx);
-/* Message of the last failed call on ctx (or of the last failed rt_create when ctx is NULL). */
+/* Message of the last failed call on ctx (or of the calling thread's last failed rt_create when ctx is NULL). */
 const char *rt_last_error(const rt_ctx *ctx);
 
 /* Replaces scene construction + the objects vector of main()

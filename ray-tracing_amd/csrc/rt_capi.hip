@@ -251,7 +251,7 @@ struct rt_ctx {
     bool probe_prune = true;
 };
 
-static std::string g_create_err;
+static thread_local std::string g_create_err; /* rt_last_error(NULL): the calling thread's last rt_create failure */
 
 /* Thresholds of the tone map for rt_resolve_kernel: T[0] = 0 and T[k] = the smallest double v >= 0 with
  * pow(v, 0.45) >= k, found by bisection over the bit patterns (which order like the values for v >= 0) with the host's
