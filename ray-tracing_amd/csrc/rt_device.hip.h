@@ -65,7 +65,7 @@ namespace rtd {
 #define RT_LEAF_CAP 320           /* leaf-item stack entries */
 #endif
 #ifndef RT_LEAF_TRIGGER
-#define RT_LEAF_TRIGGER 16        /* pending leaf items that make the next pool step a triangle step (one full step of 64 / RT_LEAF_QUAD items) */
+#define RT_LEAF_TRIGGER 0         /* pending leaf items that make the next pool step a triangle step; 0: as many as one step takes */
 #endif
 #define RT_RAY_SLOTS 128          /* rays of one query: two per lane (slot = lane, 64 + lane) */
 #define RT_NODE_BITS 25           /* record-index / leaf-count bits in a pool item (the ray slot takes the top 7) */
@@ -74,6 +74,9 @@ namespace rtd {
 #define RT_STEP_LIMIT (1u << 24)  /* pool steps of one query after which it is given up (and reported) */
 #ifndef RT_OWN_LEAF
 #define RT_OWN_LEAF 4             /* primitives per leaf of the filter trees, at most 8 (three bits in a child code) */
+#endif
+#ifndef RT_OWN_PAIR_MAX
+#define RT_OWN_PAIR_MAX 2000000   /* scenes up to this many triangles get filter-tree leaves of two triangles (rt_capi.hip) */
 #endif
 #ifndef RT_LEAF_QUAD
 #define RT_LEAF_QUAD 4            /* lanes per leaf item in a triangle step (0: as many as the item has triangles, found by a prefix sum): with
@@ -149,6 +152,7 @@ struct DScene {
     int32_t n_spheres, n_meshes;
     int32_t node_cap;  /* node-item stack entries: node_soft + the deepest tree's needs + 2 */
     int32_t node_soft; /* stack height up to which 64 items are popped per step (RT_NODE_SOFT_MIN .. RT_NODE_SOFT) */
+    int32_t own_leaf_shift; /* a leaf of the filter tree holds at most 1 << own_leaf_shift triangles (1 or 2): the lanes per leaf item of a triangle step */
     double bmax[3];   /* largest |coordinate| of any box of the scene, per axis (infinity if one is not finite) */
     uint32_t n_tris_total, n_nodes_total; /* array lengths: every index taken from the pool is checked against them */
     uint32_t n_ref_nodes;                 /* records below this index are the reference's; the rest are extension records */
@@ -734,6 +738,9 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
     const int node_soft = sc.node_soft, feed_below = sc.node_soft - RT_FEED_MARGIN;
     const int n_feed = own ? 1 : sc.n_meshes;
 
+    /* lanes per leaf item of a triangle step: as many as the longest leaf of the tree in use has triangles (two or four) */
+    const int quad_shift = (own && RT_OWN_LEAF <= RT_LEAF_QUAD) ? sc.own_leaf_shift : 2;
+    const int leaf_trigger = RT_LEAF_TRIGGER ? RT_LEAF_TRIGGER : (RT_WAVE >> quad_shift); /* one full step */
     int n_nodes = 0, n_leaves = 0; /* wave-uniform stack heights */
     int mi = 0;
     unsigned steps = 0;
@@ -802,7 +809,7 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
         }
         /* one pool step: up to 64 items */
         {
-            const bool do_leaf = (n_leaves >= (SPHP ? RT_SPH_TRIGGER : RT_LEAF_TRIGGER)) || (n_nodes == 0) ||
+            const bool do_leaf = (n_leaves >= (SPHP ? RT_SPH_TRIGGER : leaf_trigger)) || (n_nodes == 0) ||
                                  (n_leaves + (own ? 4 : 2) * RT_WAVE > RT_LEAF_CAP);
             if (do_leaf) {
                 /* A triangle step tests up to 64 (ray, triangle) pairs. Three ways from leaf items to lanes:
@@ -828,8 +835,8 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
                 int rl, take;
 #if RT_LEAF_QUAD
                 if (quad) {
-                    const int mq = n_leaves < RT_WAVE / RT_LEAF_QUAD ? n_leaves : RT_WAVE / RT_LEAF_QUAD;
-                    const int iq = lane / RT_LEAF_QUAD, rq = lane % RT_LEAF_QUAD;
+                    const int mq = n_leaves < (RT_WAVE >> quad_shift) ? n_leaves : (RT_WAVE >> quad_shift);
+                    const int iq = lane >> quad_shift, rq = lane & ((1 << quad_shift) - 1);
                     uint2 itq = make_uint2(0u, 0u);
                     int cq = 0;
                     if (iq < mq) {
@@ -840,7 +847,7 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
                     have = rq < cq;
                     tri = itq.x + (uint32_t)rq;
                     rl = (int)(itq.y >> RT_NODE_BITS);
-                    take = mq * RT_LEAF_QUAD;
+                    take = mq << quad_shift;
                     n_leaves -= mq;
                 } else
 #endif

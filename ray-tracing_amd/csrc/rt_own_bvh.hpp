@@ -269,7 +269,7 @@ struct Builder {
 inline Built build_boxes(const raw_vector<FBox> &fb, int leaf);
 
 /* the tree over the triangles tris[keep[0 .. n)] (keep == nullptr: tris[0 .. n)); `order` counts within keep */
-inline Built build(const rt_tri *tris, const int32_t *keep, int64_t n) {
+inline Built build(const rt_tri *tris, const int32_t *keep, int64_t n, int leaf = kLeaf) {
     if (n <= 0) return Built();
     const int threads = host_threads();
     PoolScope pool(n >= kSubtree ? threads : 1);
@@ -293,7 +293,7 @@ inline Built build(const rt_tri *tris, const int32_t *keep, int64_t n) {
     });
     for (char x : bad)
         if (x) return Built();
-    return build_boxes(fb, kLeaf);
+    return build_boxes(fb, leaf);
 }
 
 /* the tree over any primitives, given their (finite) boxes: the spheres of a long sphere list */
