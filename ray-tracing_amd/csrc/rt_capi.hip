@@ -457,7 +457,7 @@ static int32_t ext_split(const rt_tri *tris, int32_t first, int32_t n, std::vect
 }
 
 /* The tree over a long sphere list: the filter tree's builder (rt_own_bvh.hpp: binned surface-area cuts, four children per
- * record, leaves of at most four spheres) over the spheres' boxes; the spheres are re-ordered into its leaf order. `reach`
+ * record, leaves of RT_SPH_LEAF = one sphere) over the spheres' boxes; the spheres are re-ordered into its leaf order. `reach`
  * is how far from the coordinate origin a ray may start for the margin of the boxes to hold: a hundred thousand times the
  * smallest radius, less the largest centre coordinate. (Sphere::intersect accepts delta = b^2 - 4c >= 0 as computed; its
  * rounding error is below 64 * 2^-53 |C - O|^2, so an accepted ray passes the centre within R sqrt(1 + 16 * 2^-53 |C - O|^2 / R^2)

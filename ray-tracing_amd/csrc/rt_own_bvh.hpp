@@ -4,7 +4,7 @@
  * The reference's BVH (raytracer.cpp:244-291) decides which triangles a ray may hit; its quality is poor
  * (one tree per mesh, median cuts, leaves of up to hundreds of triangles). The traversal therefore runs on
  * a second tree built here over ALL triangles of the scene - binned surface-area cuts, leaves of at most
- * four triangles, triangles copied into this tree's own order - and uses it only to find candidate hits:
+ * two or four triangles (by scene size), triangles copied into this tree's own order - and uses it only to find candidate hits:
  * a ray is kept out of a box just when it certainly misses it. Whether the reference would have reached
  * the winning triangle is then checked on the reference's own leaf box (rt_device.hip.h: rays_end).
  */
