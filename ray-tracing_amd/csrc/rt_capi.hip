@@ -249,6 +249,7 @@ struct rt_ctx {
     int n_cus = 256;
     int waves_per_cu = 8;
     bool probe_prune = true;
+    int force_own_leaf = 0; /* tests: triangles per leaf of the next uploads' filter trees (0: by scene size) */
 };
 
 static thread_local std::string g_create_err; /* rt_last_error(NULL): the calling thread's last rt_create failure */
@@ -790,7 +791,7 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
                 /* Leaves of two triangles up to RT_OWN_PAIR_MAX triangles, of RT_OWN_LEAF beyond: a triangle step then runs two
                  * lanes per leaf item instead of four (fuller steps: +1.5 % on the 0.7 M-triangle scene), for 40 % more
                  * records - which is what costs on the 5 M-triangle scene (-1 %, set-up +10 %). */
-                const int own_leaf = ((int64_t)keep.size() <= RT_OWN_PAIR_MAX && RT_OWN_LEAF > 2) ? 2 : RT_OWN_LEAF;
+                const int own_leaf = c->force_own_leaf ? c->force_own_leaf : ((int64_t)keep.size() <= RT_OWN_PAIR_MAX && RT_OWN_LEAF > 2) ? 2 : RT_OWN_LEAF;
                 rtown::Built own = rtown::build(s->tris, keep.data(), (int64_t)keep.size(), own_leaf);
                 d.own_leaf_shift = own_leaf <= 2 ? 1 : 2;
                 rtown::stage_tick("rt_upload_scene: filter tree build");
@@ -1280,6 +1281,14 @@ int rt_debug_filter_tree_hash(rt_ctx *c, uint64_t *out) {
 int rt_debug_probe_prune(rt_ctx *c, int on) {
     if (!c) return RT_E_INVALID;
     c->probe_prune = on != 0;
+    return RT_OK;
+}
+
+/* not part of the public header: the filter trees of the following uploads get leaves of 2 or 4 triangles whatever the scene's
+ * size (0: back to the rule), so that tests reach both forms of the triangle step on small scenes (tests/ only) */
+int rt_debug_own_leaf(rt_ctx *c, int leaf) {
+    if (!c || (leaf != 0 && leaf != 2 && leaf != 4) || leaf > RT_OWN_LEAF) return RT_E_INVALID;
+    c->force_own_leaf = leaf;
     return RT_OK;
 }
 

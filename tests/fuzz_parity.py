@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Random scenes against the CPU checker: python tests/fuzz_parity.py [first_seed [n_scenes]]
+"""Random scenes against the CPU checker: python tests/fuzz_parity.py [first_seed [n_scenes [triangles per filter-tree leaf: 0 = by scene size, 4]]]
 
 Every scene is a random mix of what the hand-written tests cover one at a time: few or many spheres (the list staged in
 LDS, or the sphere tree), equal and nested spheres, zero to four meshes of 12 to 24 300 triangles, a mesh repeated in place
@@ -87,7 +87,16 @@ def make_rays(rng, verts, n):
     return np.ascontiguousarray(np.concatenate(rays))
 
 
-def check(seed, gpu):
+def check(seed, gpu, own_leaf=0):
+    """own_leaf: 0 = the filter tree's leaf size by the library's rule (two triangles at these sizes), 4 = the form large scenes get"""
+    assert rta.lib.rt_debug_own_leaf(gpu._h, own_leaf) == 0
+    try:
+        return _check(seed, gpu)
+    finally:
+        rta.lib.rt_debug_own_leaf(gpu._h, 0)
+
+
+def _check(seed, gpu):
     s, verts, n_sph, n_mesh, notes = make_scene(seed)
     rng = np.random.default_rng(seed + 100000)
     orc = ob.OracleScene(scenes.export_objects(s), s.I, s.L, math="portable")
@@ -126,9 +135,10 @@ def check(seed, gpu):
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    own_leaf = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     gpu = rta.Renderer(0)
     for seed in range(first, first + n):
-        if not check(seed, gpu):
+        if not check(seed, gpu, own_leaf):
             sys.exit(1)
     print("all %d scenes equal" % n)
 

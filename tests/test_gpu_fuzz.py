@@ -17,3 +17,9 @@ _spec.loader.exec_module(fuzz)
 @pytest.mark.parametrize("seed", [3, 8, 27, 30, 34, 35, 36])
 def test_random_scene(gpu, seed):
     assert fuzz.check(seed, gpu)
+
+
+@pytest.mark.parametrize("seed", [8, 27, 34, 36])
+def test_random_scene_with_the_large_scene_tree(gpu, seed):
+    """the same with filter-tree leaves of four triangles and four lanes per leaf item, the form scenes beyond 2 M triangles get"""
+    assert fuzz.check(seed, gpu, own_leaf=4)
