@@ -104,6 +104,7 @@ struct Decoder {
     }
     int bits(int n) {
         if (n == 0) return 0;
+        if (n < 0 || n > 16) bad("bit count out of range"); /* a category or run length from a corrupt table */
         if (bitcnt < n) fill();
         const int v = (int)(bitbuf >> (32 - n));
         bitbuf <<= n;
@@ -251,17 +252,28 @@ struct Decoder {
 
     /* ---- inverse DCT: 12-bit constants, columns to 2 extra bits, rows to 8-bit samples with the level shift ---- */
     static int fix(float c) { return (int)(c * 4096 + 0.5); }
-    struct Idct1 { int x0, x1, x2, x3, t0, t1, t2, t3; };
-    static Idct1 idct1(int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7) {
+    /* int with wrap-around arithmetic: the coefficients of a corrupt file can push the inverse DCT past 32 bits, which must
+     * be a wrong picture and not undefined behaviour; for every valid file nothing overflows and the values are the same */
+    struct wint {
+        int v;
+        wint(int x = 0) : v(x) {}
+        friend wint operator+(wint a, wint b) { return wint((int)((uint32_t)a.v + (uint32_t)b.v)); }
+        friend wint operator-(wint a, wint b) { return wint((int)((uint32_t)a.v - (uint32_t)b.v)); }
+        friend wint operator*(wint a, wint b) { return wint((int)((uint32_t)a.v * (uint32_t)b.v)); }
+        wint &operator+=(wint b) { return *this = *this + b; }
+        friend wint operator>>(wint a, int sh) { return wint(a.v >> sh); }
+    };
+    struct Idct1 { wint x0, x1, x2, x3, t0, t1, t2, t3; };
+    static Idct1 idct1(wint s0, wint s1, wint s2, wint s3, wint s4, wint s5, wint s6, wint s7) {
         Idct1 o;
-        int p2 = s2, p3 = s6;
-        int p1 = (p2 + p3) * fix(0.5411961f);
-        int t2 = p1 + p3 * fix(-1.847759065f);
-        int t3 = p1 + p2 * fix(0.765366865f);
+        wint p2 = s2, p3 = s6;
+        wint p1 = (p2 + p3) * fix(0.5411961f);
+        wint t2 = p1 + p3 * fix(-1.847759065f);
+        wint t3 = p1 + p2 * fix(0.765366865f);
         p2 = s0;
         p3 = s4;
-        int t0 = (p2 + p3) * 4096;
-        int t1 = (p2 - p3) * 4096;
+        wint t0 = (p2 + p3) * 4096;
+        wint t1 = (p2 - p3) * 4096;
         o.x0 = t0 + t3;
         o.x3 = t0 - t3;
         o.x1 = t1 + t2;
@@ -271,10 +283,10 @@ struct Decoder {
         t2 = s3;
         t3 = s1;
         p3 = t0 + t2;
-        int p4 = t1 + t3;
+        wint p4 = t1 + t3;
         p1 = t0 + t3;
         p2 = t1 + t2;
-        const int p5 = (p3 + p4) * fix(1.175875602f);
+        const wint p5 = (p3 + p4) * fix(1.175875602f);
         t0 = t0 * fix(0.298631336f);
         t1 = t1 * fix(2.053119869f);
         t2 = t2 * fix(3.072711026f);
@@ -295,14 +307,14 @@ struct Decoder {
         for (int i = 0; i < 8; i++) {
             Idct1 a = idct1(d[i], d[8 + i], d[16 + i], d[24 + i], d[32 + i], d[40 + i], d[48 + i], d[56 + i]);
             a.x0 += 512; a.x1 += 512; a.x2 += 512; a.x3 += 512;
-            val[i] = (a.x0 + a.t3) >> 10;
-            val[56 + i] = (a.x0 - a.t3) >> 10;
-            val[8 + i] = (a.x1 + a.t2) >> 10;
-            val[48 + i] = (a.x1 - a.t2) >> 10;
-            val[16 + i] = (a.x2 + a.t1) >> 10;
-            val[40 + i] = (a.x2 - a.t1) >> 10;
-            val[24 + i] = (a.x3 + a.t0) >> 10;
-            val[32 + i] = (a.x3 - a.t0) >> 10;
+            val[i] = ((a.x0 + a.t3) >> 10).v;
+            val[56 + i] = ((a.x0 - a.t3) >> 10).v;
+            val[8 + i] = ((a.x1 + a.t2) >> 10).v;
+            val[48 + i] = ((a.x1 - a.t2) >> 10).v;
+            val[16 + i] = ((a.x2 + a.t1) >> 10).v;
+            val[40 + i] = ((a.x2 - a.t1) >> 10).v;
+            val[24 + i] = ((a.x3 + a.t0) >> 10).v;
+            val[32 + i] = ((a.x3 - a.t0) >> 10).v;
         }
         for (int i = 0; i < 8; i++) {
             const int *v = val + 8 * i;
@@ -310,14 +322,14 @@ struct Decoder {
             Idct1 a = idct1(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
             const int bias = 65536 + (128 << 17); /* rounding of the 17-bit shift + the level shift by 128 */
             a.x0 += bias; a.x1 += bias; a.x2 += bias; a.x3 += bias;
-            o[0] = clamp8((a.x0 + a.t3) >> 17);
-            o[7] = clamp8((a.x0 - a.t3) >> 17);
-            o[1] = clamp8((a.x1 + a.t2) >> 17);
-            o[6] = clamp8((a.x1 - a.t2) >> 17);
-            o[2] = clamp8((a.x2 + a.t1) >> 17);
-            o[5] = clamp8((a.x2 - a.t1) >> 17);
-            o[3] = clamp8((a.x3 + a.t0) >> 17);
-            o[4] = clamp8((a.x3 - a.t0) >> 17);
+            o[0] = clamp8(((a.x0 + a.t3) >> 17).v);
+            o[7] = clamp8(((a.x0 - a.t3) >> 17).v);
+            o[1] = clamp8(((a.x1 + a.t2) >> 17).v);
+            o[6] = clamp8(((a.x1 - a.t2) >> 17).v);
+            o[2] = clamp8(((a.x2 + a.t1) >> 17).v);
+            o[5] = clamp8(((a.x2 - a.t1) >> 17).v);
+            o[3] = clamp8(((a.x3 + a.t0) >> 17).v);
+            o[4] = clamp8(((a.x3 - a.t0) >> 17).v);
         }
     }
 

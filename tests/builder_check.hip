@@ -1,4 +1,4 @@
-/* Host-side check of the filter-tree builder (ray-tracing_amd/csrc/rt_own_bvh.hpp), built and run by tests/test_builder_host.py
+/* Host-side check of the filter-tree builder (ray-tracing_amd/csrc/rt_own_bvh.hpp), built and run by tests/test_host_sanitizers.py
  * with the address and undefined-behaviour sanitizers: for 1 to 200 000 random triangles (a third of them identical, which
  * sends ranges to the median fallback), an index subset, leaves of 1 / 2 / 4 and 1 / 3 / 8 host threads it checks that the
  * order is a permutation, that the leaves cover every primitive exactly once with at most `leaf` each, that children come

@@ -1,0 +1,57 @@
+"""Host code under the address and undefined-behaviour sanitizers, on the CPU: the filter-tree builder and its worker pool
+(tests/builder_check.hip: structure of the trees, independence of the thread count) and the JPEG texture decoder on mutated
+files (tests/jpeg_fuzz.cpp)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_builder_structure_and_thread_independence(tmp_path):
+    exe = str(tmp_path / "builder_check")
+    cmd = [HIPCC, "-O1", "-g", "-std=c++17", "-Xarch_host", "-fsanitize=address", "-Xarch_host", "-fsanitize=undefined", "-Xarch_host",
+           "-fno-sanitize-recover=undefined", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "ray-tracing_amd", "csrc"),
+           "--offload-arch=gfx950", os.path.join(ROOT, "tests", "builder_check.hip"), "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    out = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "builder checks passed" in out.stdout
+
+
+def test_jpeg_decoder_on_mutated_files(tmp_path):
+    PIL = pytest.importorskip("PIL.Image")
+    import numpy as np
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("g++ not installed")
+    rng = np.random.default_rng(3)
+    files = []
+    for size in ((64, 64), (33, 17), (8, 8)):
+        for mode in ("RGB", "L"):
+            a = (rng.random((size[1], size[0], 3)) * 255).astype(np.uint8)
+            img = PIL.fromarray(a).resize((size[0] * 2, size[1] * 2)).resize(size)
+            if mode == "L":
+                img = img.convert("L")
+            for sub in (0, 1, 2):
+                for prog in (False, True):
+                    fn = str(tmp_path / ("t%d.jpg" % len(files)))
+                    kw = dict(quality=30 + 20 * sub, progressive=prog, optimize=bool(len(files) % 2))
+                    if mode == "RGB":
+                        kw["subsampling"] = sub
+                    img.save(fn, "JPEG", **kw)
+                    files.append(fn)
+    exe = str(tmp_path / "jpeg_fuzz")
+    cmd = [gxx, "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-I" + os.path.join(ROOT, "ray-tracing_amd", "host"), "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "jpeg_fuzz.cpp"), os.path.join(ROOT, "ray-tracing_amd", "host", "rt_jpeg.cpp"), "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", ITERS="40")
+    out = subprocess.run([exe] + files, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.stdout.startswith("decoded ")
