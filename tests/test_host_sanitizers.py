@@ -1,6 +1,6 @@
 """Host code under the address and undefined-behaviour sanitizers, on the CPU: the filter-tree builder and its worker pool
 (tests/builder_check.hip: structure of the trees, independence of the thread count) and the JPEG texture decoder on mutated
-files (tests/jpeg_fuzz.cpp)."""
+files (tests/jpeg_fuzz.cpp), the OBJ reader, buildBVH and flatten on mutated files (tests/obj_fuzz.cpp)."""
 import os
 import shutil
 import subprocess
@@ -55,3 +55,19 @@ def test_jpeg_decoder_on_mutated_files(tmp_path):
     out = subprocess.run([exe] + files, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert out.stdout.startswith("decoded ")
+
+
+def test_obj_reader_on_mutated_files(tmp_path):
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("g++ not installed")
+    exe = str(tmp_path / "obj_fuzz")
+    cmd = [gxx, "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-I" + os.path.join(ROOT, "ray-tracing_amd", "host"), "-I" + os.path.join(ROOT, "ray-tracing_amd", "csrc"), "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "obj_fuzz.cpp"), os.path.join(ROOT, "ray-tracing_amd", "host", "rt_host.cpp"),
+           os.path.join(ROOT, "ray-tracing_amd", "host", "rt_jpeg.cpp"), "-o", exe, "-lpthread"]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", ITERS="600", OBJ_TMP=str(tmp_path / "mutant.obj"))
+    out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "reader_cases.obj")], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.stdout.startswith("read ")
