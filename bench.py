@@ -277,7 +277,10 @@ def main():
                                     "tris_per_path": round(c["tris"] / c["paths"], 2), "TFLOPs_equivalent": round(ref_tflops, 4),
                                     "frac_equivalent": round(ref_tflops / PEAK_FP64_VECTOR_TFLOPS, 5),
                                     "note": "the unpruned reference algorithm's flops divided by this kernel's time: a speed-up-inclusive figure, not a utilisation"},
-            "rays_per_path": round(c["rays"] / c["paths"], 3)}
+            "rays_per_path": round(c["rays"] / c["paths"], 3), "rays_traced_per_path": round(g["rays"] / g["paths"], 3),
+            "rays_note": "rays_per_path = rays the reference traces; rays_traced_per_path = rays this kernel traces: the shadow ray of a vertex whose "
+                         "direct term is exactly zero and the ray beyond the depth limit (intersected, then dropped, raytracer.cpp:960-963) are left out, "
+                         "the image keeps every bit"}
         # HBM-side bytes per launch: not collectable inside this process (PMC needs rocprofv3 around it). Taken from the
         # committed counter pass of this same command ONLY if that pass was made with this very library build (hash stored
         # in the summary); FETCH_SIZE is in KB of 64 B requests, doubled for gfx950's 128-byte requests. Null otherwise.
@@ -327,7 +330,7 @@ def main():
                           "scene_bytes_hbm": info["bytes"], "scene_bytes_device": sizes[0], "traversal_records": sizes[1],
                           "filter_tree_records": sizes[2], "waves_per_cu": min(occ_b.value, 8), "lds_bytes_per_wave": occ_l.value,
                           "setup": setup},
-               "rays_per_s": round(value * 1e6 * c["rays"] / c["paths"], 1),
+               "rays_per_s": round(value * 1e6 * g["rays"] / g["paths"], 1),
                "time_to_image": tti,
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out))

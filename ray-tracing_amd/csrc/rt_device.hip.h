@@ -1347,9 +1347,16 @@ __device__ __forceinline__ void path_fresh(const RenderArgs &ra, Path &q, int i,
 /* One step of Scene::getColor (raytracer.cpp:953-1093) given the answers of the rays that were traced: first the
  * shadow ray of the pending diffuse vertex (hs), then the path segment (h), in the order the recursion adds their
  * terms. Leaves the next ray(s) in the state or ends the sample (fresh = true). */
+/* lean: rays whose answer cannot change the sample are not traced (the reference traces them and drops the answer):
+ * - the shadow ray of a vertex whose direct term is exactly zero (surface or light sample facing away: nee == 0, so the
+ *   sum gets + 0 whether or not the ray is occluded) - marked by sh_limit = 0, see shadow_wanted();
+ * - the ray that leaves a vertex at depth max_rebond: Scene::getColor intersects it first and then returns zero because
+ *   of its depth (raytracer.cpp:960-963).
+ * The sample's value keeps every bit; only the work counters and the path trace differ, so the callers set lean only with
+ * pruning on and no trace asked for. */
 template <bool CNT, bool PLAIN = false, typename SP>
 __device__ __forceinline__ void path_advance(const DScene &sc, SP sph, const RenderArgs &ra, Path &q, bool inter,
-                                             const HitRec &h, bool inter_s, const HitRec &hs, Cnt &cnt, int &branch) {
+                                             const HitRec &h, bool inter_s, const HitRec &hs, Cnt &cnt, int &branch, bool lean) {
     const rt_params &p = ra.p;
     const uint32_t fl = PLAIN ? 0u : p.flags;
     const double epsilon = p.epsilon;
@@ -1453,7 +1460,8 @@ __device__ __forceinline__ void path_advance(const DScene &sc, SP sph, const Ren
                 q.nee = divs(muls(muls(smul(sc.I / (4 * RT_PI * RT_PI * R2), divs(s.albedo, RT_PI)), smax(0., dot(N, Px))), J), proba);
                 q.sh_limit = d - p.shadow_bias;
             }
-            if (!(fl & RT_F_NO_INDIRECT)) { /* :1086-1087; its two draws follow the light's two */
+            if (lean && q.nee.x == 0 && q.nee.y == 0 && q.nee.z == 0) q.sh_limit = 0;
+            if (!(fl & RT_F_NO_INDIRECT) && !(lean && q.rebond >= p.max_rebond)) { /* :1086-1087; its two draws follow the light's two */
                 double u1 = rng_uniform(q.key, q.ctr), u2 = rng_uniform(q.key, q.ctr + 1);
                 q.ctr += 2;
                 q.ru = random_cos(u1, u2, N);
@@ -1467,12 +1475,19 @@ __device__ __forceinline__ void path_advance(const DScene &sc, SP sph, const Ren
             q.shadow = true;
         }
     }
+    if (lean && !q.shadow && q.rebond > p.max_rebond) done = true; /* a mirror or refraction ray beyond the depth limit */
     if (done) {
         q.acc = add(q.acc, q.Lsum);
         q.k++;
         q.fresh = true;
     }
 }
+
+/* Whether the pending vertex's shadow ray has to be traced. Its answer is used only as "hit && t < sh_limit"
+ * (raytracer.cpp:1073), and no hit has a negative t (Sphere::intersect returns t2 >= 0 or t1 > 0, a triangle needs
+ * localt > 0), so a limit that is not positive - too close to the light sample, or set to zero by path_advance because the
+ * vertex's direct term is zero - makes the test false whatever is hit. */
+__device__ __forceinline__ bool shadow_wanted(const Path &q, bool lean) { return q.shadow && !(lean && !(q.sh_limit > 0)); }
 
 /* Single-kernel form: sum of the radiance of samples k0 .. k0+nk-1 of pixel (i, j), added in that
  * order (the k loop of raytracer.cpp:1464-1486). Called by all 64 lanes of the wave; lanes with
@@ -1483,6 +1498,8 @@ __device__ __forceinline__ V3 trace_pixel(const DScene &sc, const DScene &cold, 
     Path q;
     path_begin(q, k0, live);
     const int kend = k0 + nk;
+    const bool prune = !(ra.p.flags & RT_F_NO_PRUNE);
+    const bool lean = prune && trace == nullptr; /* the path trace lists every ray the reference traces */
     uint64_t sp0 = 0;
     while (true) {
         if (CNT) sp0 = RT_STAMP();
@@ -1491,8 +1508,8 @@ __device__ __forceinline__ V3 trace_pixel(const DScene &sc, const DScene &cold, 
         if (CNT) cnt.cyc_fresh += RT_STAMP() - sp0;
         HitRec h, hs;
         const RayQ qa = RayQ{!q.finished && q.segment, q.rC, q.ru, 1E10, false};
-        const RayQ qb = RayQ{!q.finished && q.shadow, q.shC, q.shU, q.sh_limit, true};
-        scene_closest_wave<CNT, SPH>(sc, cold, w, sph, roots, qa, qb, !(ra.p.flags & RT_F_NO_PRUNE), h, hs, cnt);
+        const RayQ qb = RayQ{!q.finished && shadow_wanted(q, lean), q.shC, q.shU, q.sh_limit, true};
+        scene_closest_wave<CNT, SPH>(sc, cold, w, sph, roots, qa, qb, prune, h, hs, cnt);
         if (CNT) sp0 = RT_STAMP();
         if (!q.finished) {
             /* the probe's path trace (rt_sample_trace; nk == 1): entry d belongs to the query at recursion depth d */
@@ -1502,7 +1519,7 @@ __device__ __forceinline__ V3 trace_pixel(const DScene &sc, const DScene &cold, 
             const uint32_t draws = q.ctr;
             const bool occluded = inter_s && hs.t < q.sh_limit;
             int branch;
-            path_advance<CNT>(cold, sph, ra, q, inter, h, inter_s, hs, cnt, branch);
+            path_advance<CNT>(cold, sph, ra, q, inter, h, inter_s, hs, cnt, branch, lean);
             if (trace) {
                 if (had_shadow && occluded && d_vertex < RT_TRACE_LEN) trace[4 * d_vertex + 3] = RT_TRACE_DIFFUSE_SHADOWED;
                 if (had_seg && d_seg < RT_TRACE_LEN) {
@@ -1553,6 +1570,7 @@ __device__ __forceinline__ void render_persistent(const DScene &sc, const DScene
     bool have = false, exhausted = false;
     int i = 0, j = 0;
     int cur = 0, end = 0; /* wave-uniform: the part of the last tile request not handed out yet */
+    const bool prune = PLAIN ? true : !(ra.p.flags & RT_F_NO_PRUNE); /* also: rays without effect are not traced (path_advance) */
     uint64_t sp0 = 0;
     while (true) {
         if (CNT) sp0 = RT_STAMP();
@@ -1605,11 +1623,11 @@ __device__ __forceinline__ void render_persistent(const DScene &sc, const DScene
         if (CNT) cnt.cyc_fresh += RT_STAMP() - sp0;
         HitRec h, hs;
         const RayQ qa = RayQ{!q.finished && q.segment, q.rC, q.ru, 1E10, false};
-        const RayQ qb = RayQ{!q.finished && q.shadow, q.shC, q.shU, q.sh_limit, true};
-        scene_closest_wave<CNT, SPH>(sc, cold, w, sph, roots, qa, qb, PLAIN ? true : !(ra.p.flags & RT_F_NO_PRUNE), h, hs, cnt);
+        const RayQ qb = RayQ{!q.finished && shadow_wanted(q, prune), q.shC, q.shU, q.sh_limit, true};
+        scene_closest_wave<CNT, SPH>(sc, cold, w, sph, roots, qa, qb, prune, h, hs, cnt);
         if (CNT) sp0 = RT_STAMP();
         int branch; /* unused here */
-        if (!q.finished) path_advance<CNT, PLAIN>(cold, sph, ra, q, h.obj != INT32_MAX, h, hs.obj != INT32_MAX, hs, cnt, branch);
+        if (!q.finished) path_advance<CNT, PLAIN>(cold, sph, ra, q, h.obj != INT32_MAX, h, hs.obj != INT32_MAX, hs, cnt, branch, prune);
         if (CNT) cnt.cyc_shade += RT_STAMP() - sp0;
     }
 }
