@@ -91,6 +91,13 @@ namespace rtd {
                                      leaf step needs no prefix sum to spread items over lanes (cfg5: +5.6 % against 4) */
 #endif
 #ifndef RT_EXT_LEAF
+#ifndef RT_TRAV_PRIO
+#define RT_TRAV_PRIO 1            /* issue priority of a wave while it is in the pool traversal, whose steps are chains of dependent
+                                     instructions (elsewhere RT_SHADE_PRIO): 1, 2, 3 all +1.2 % on the battle scene; the reverse -0.7 % */
+#endif
+#ifndef RT_SHADE_PRIO
+#define RT_SHADE_PRIO 0
+#endif
 #define RT_EXT_LEAF 4             /* reference leaves with more triangles than this get extension records down to this size */
 #endif
 static_assert(RT_NODE_SOFT_MIN > RT_FEED_MARGIN + RT_WAVE && RT_NODE_SOFT_MIN <= RT_NODE_SOFT, "the feed needs room for a mesh above a useful stack height");
@@ -844,6 +851,9 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
                         cq = (int)(itq.y & RT_LOW_MASK);
                         if (w->leaf_t[n_leaves - 1 - iq] > w->thrf[itq.y >> RT_NODE_BITS]) cq = 0;
                     }
+#ifdef RT_DIAG_STALE
+                    if (CNT && !SPHP) { cnt.dbg[3] += __popcll(__ballot(iq < mq && rq == 0)); cnt.dbg[2] += __popcll(__ballot(iq < mq && rq == 0 && cq == 0)); }
+#endif
                     have = rq < cq;
                     tri = itq.x + (uint32_t)rq;
                     rl = (int)(itq.y >> RT_NODE_BITS);
@@ -993,6 +1003,9 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     const uint64_t t = RT_STAMP(); cnt.dbg[1] += t - st0; st0 = t;
                 }
+#ifdef RT_DIAG_STALE /* diagnostic: popped node items / those that had fallen behind their ray's threshold */
+                if (CNT && !SPHP) { cnt.dbg[1] += __popcll(__ballot(have)); cnt.dbg[0] += __popcll(__ballot(have && __uint_as_float(it.y) > w->thrf[rl])); }
+#endif
                 wide_children(sc, w, lane, have, rl, __uint_as_float(it.y), q0, q1, q2, q3, q4, q5, ch, n_nodes, n_leaves);
                 wave_sync();
                 if (CNT) {
@@ -1180,10 +1193,19 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScen
     if (CNT) { const uint64_t t = RT_STAMP(); cnt.cyc_roots += t - st0; st0 = t; } /* spheres and ray constants count with the roots */
     if (sc.n_meshes == 0) return;
     {
-        const unsigned long long mask_a = wave_ballot(qa.active), mask_b = wave_ballot(qb.active);
+        /* a shadow ray that a sphere already blocks before tmax is settled: whatever the meshes hold, "hit && t < tmax" stays
+         * true (its table entry keeps "no triangle", so rays_end leaves the sphere hit in place) */
+        const bool settled_b = prune && qb.anyhit && hb.obj != INT32_MAX && hb.t < qb.tmax;
+        const unsigned long long mask_a = wave_ballot(qa.active), mask_b = wave_ballot(qb.active && !settled_b);
         /* inlined on purpose: as a real call (scene fields from the LDS copy, the path state saved around it) the kernel
          * ran 9 % slower at the same occupancy, and compiled for three waves per SIMD 24 % slower */
+#if RT_TRAV_PRIO != RT_SHADE_PRIO
+        __builtin_amdgcn_s_setprio(RT_TRAV_PRIO);
+#endif
         pool_traverse<CNT>(sc, cold, w, roots, own, prune, mask_a, mask_b, cnt, st0);
+#if RT_TRAV_PRIO != RT_SHADE_PRIO
+        __builtin_amdgcn_s_setprio(RT_SHADE_PRIO);
+#endif
     }
     bool da, db;
     rays_end(cold, w, lane, qa, qb, own, ha, hb, da, db);
@@ -1616,18 +1638,19 @@ __device__ __forceinline__ void render_persistent(const DScene &sc, const DScene
             cur = (cur + taken < end) ? cur + taken : end;
         }
         path_fresh<CNT, PLAIN>(ra, q, i, j, kend_l, cnt);
-        if (__ballot(!q.finished) == 0ull) {
+        const bool tracing = !q.finished;
+        if (__ballot(tracing) == 0ull) {
             if (__ballot(!exhausted || have) == 0ull) break;
             continue; /* nothing to trace this round: only bookkeeping (pixels ended or were just assigned) */
         }
         if (CNT) cnt.cyc_fresh += RT_STAMP() - sp0;
         HitRec h, hs;
-        const RayQ qa = RayQ{!q.finished && q.segment, q.rC, q.ru, 1E10, false};
-        const RayQ qb = RayQ{!q.finished && shadow_wanted(q, prune), q.shC, q.shU, q.sh_limit, true};
+        const RayQ qa = RayQ{tracing && q.segment, q.rC, q.ru, 1E10, false};
+        const RayQ qb = RayQ{tracing && shadow_wanted(q, prune), q.shC, q.shU, q.sh_limit, true};
         scene_closest_wave<CNT, SPH>(sc, cold, w, sph, roots, qa, qb, prune, h, hs, cnt);
         if (CNT) sp0 = RT_STAMP();
         int branch; /* unused here */
-        if (!q.finished) path_advance<CNT, PLAIN>(cold, sph, ra, q, h.obj != INT32_MAX, h, hs.obj != INT32_MAX, hs, cnt, branch, prune);
+        if (tracing) path_advance<CNT, PLAIN>(cold, sph, ra, q, h.obj != INT32_MAX, h, hs.obj != INT32_MAX, hs, cnt, branch, prune);
         if (CNT) cnt.cyc_shade += RT_STAMP() - sp0;
     }
 }
