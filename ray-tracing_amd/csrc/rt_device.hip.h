@@ -675,11 +675,14 @@ __device__ __forceinline__ void wide_children(const DScene &sc, WaveLDS *w, int 
     const float iux = w->rayf[0][rl], iuy = w->rayf[1][rl], iuz = w->rayf[2][rl];
     const float ncx = w->rayf[3][rl], ncy = w->rayf[4][rl], ncz = w->rayf[5][rl];
     const float tolf = __builtin_fabsf(w->tolf[rl]); /* NaN: then nothing is ever certain */
-    have = have && !(item_t > thrf); /* fallen behind the threshold since it was pushed */
+    /* The lanes' yes/no answers are kept as wave masks (one compare each, combined by scalar instructions) and turned back
+     * into lane predicates only where something is stored: the ballot of a combined lane condition costs two vector
+     * instructions more than the ballot of a plain compare. */
+    const unsigned long long bh = wave_ballot(have) & wave_ballot(!(item_t > thrf)); /* not fallen behind the threshold since it was pushed */
     const float bx[24] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w,
                           q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w};
     const uint32_t code[4] = {ch.x, ch.y, ch.z, ch.w};
-    bool pn[4], pl[4];
+    unsigned long long mn[4], ml[4];
     float f[4];
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -688,35 +691,35 @@ __device__ __forceinline__ void wide_children(const DScene &sc, WaveLDS *w, int 
         const float t1z = __builtin_fmaf(bx[6 * c + 2], iuz, ncz), t2z = __builtin_fmaf(bx[6 * c + 5], iuz, ncz);
         const float tMax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
         const float tMin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
-        const bool miss = (tMax - tMin < -tolf) | (tMax < -tolf);
+        /* certain miss: tMax - tMin < -tolf or tMax < -tolf (a NaN on either side never says "miss") */
+        const unsigned long long not_missed = wave_ballot(!(fminf(tMax, tMax - tMin) < -tolf));
         const float tlo = tMin - tolf;
-        const bool go = have & (code[c] != RT_CHILD_EMPTY) & !miss & !(tlo > thrf); /* no short cuts: straight-line code */
-        pn[c] = go & !(code[c] >> 31);
-        pl[c] = go & (bool)(code[c] >> 31);
+        const unsigned long long go = bh & not_missed & wave_ballot(!(tlo > thrf));
+        /* child codes: record (top bit clear), leaf (top bit set), empty (all ones) */
+        const unsigned long long is_rec = wave_ballot((int32_t)code[c] >= 0), not_empty = wave_ballot(code[c] != RT_CHILD_EMPTY);
+        mn[c] = go & is_rec;
+        ml[c] = go & ~is_rec & not_empty;
         f[c] = tlo; /* already below the real entry parameter: the tolerance exceeds the error of tMin by 1.7e-7 M, the rounding of
                        the subtraction is 6e-8 M at most */
     }
-    /* Places on the stacks: all first children, then all second children, ... - one ballot per child and kind, the
-     * lane's place among them by mbcnt, the offsets by scalar popcounts. No prefix sum over the lanes is needed. */
+    /* Places on the stacks: all first children, then all second children, ... - the lane's place among them by mbcnt,
+     * the offsets by scalar popcounts. No prefix sum over the lanes is needed. */
     int jn[4], jl[4];
     int tn = n_nodes, tl = n_leaves;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        /* one ballot of a combined condition costs two instructions more than the ballot of a plain compare */
-        const unsigned long long mg = wave_ballot(pn[c] | pl[c]), mleaf = wave_ballot((int32_t)code[c] < 0);
-        const unsigned long long mn = mg & ~mleaf, ml = mg & mleaf;
-        jn[c] = tn + rank_in(mn);
-        jl[c] = tl + rank_in(ml);
-        tn += __popcll(mn);
-        tl += __popcll(ml);
+        jn[c] = tn + rank_in(mn[c]);
+        jl[c] = tl + rank_in(ml[c]);
+        tn += __popcll(mn[c]);
+        tl += __popcll(ml[c]);
     }
     if (tn > sc.node_cap || tl > RT_LEAF_CAP) { /* cannot happen for a validated scene; never write past the stacks */
         if (lane == 0) atomicOr(sc.overflow, 1);
     } else {
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            if (pn[c]) w->node[jn[c]] = make_uint2(code[c] | ((uint32_t)rl << RT_NODE_BITS), __float_as_uint(f[c]));
-            if (pl[c]) {
+            if (__builtin_amdgcn_inverse_ballot_w64(mn[c])) w->node[jn[c]] = make_uint2(code[c] | ((uint32_t)rl << RT_NODE_BITS), __float_as_uint(f[c]));
+            if (__builtin_amdgcn_inverse_ballot_w64(ml[c])) {
                 w->leaf[jl[c]] = make_uint2(code[c] & 0x0FFFFFFFu, (((code[c] >> 28) & 7u) + 1u) | ((uint32_t)rl << RT_NODE_BITS));
                 w->leaf_t[jl[c]] = f[c];
             }
