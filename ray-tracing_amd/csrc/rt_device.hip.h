@@ -414,8 +414,7 @@ struct WaveLDS {
 #ifdef RT_LDS_PAD /* diagnostic: fewer resident waves per CU */
     double lds_pad[RT_LDS_PAD / 8];
 #endif
-    uint2 leaf[RT_LEAF_CAP];              /* leaf items: x = first triangle, y = count | ray slot << 25 */
-    float leaf_t[RT_LEAF_CAP];            /* entry parameter of the leaf's box, rounded down */
+    uint2 leaf[RT_LEAF_CAP];              /* leaf items, see leaf_item() */
     uint2 node[1];                        /* node items: x = record index | ray slot << 25, y = entry parameter (float bits, rounded
                                              down); node_cap entries, then the staged spheres */
 };
@@ -666,6 +665,20 @@ __device__ __forceinline__ RayKf ray_k_from_lds(const WaveLDS *w, int slot) {
     return k;
 }
 
+/* A leaf item of the pool: x = first primitive (25 bits) | count - 1 in bits 28-30 (bit 31 is ignored: a leaf code of the
+ * filter tree can be stored as it is), y = the entry parameter of the leaf's box as float bits with the ray slot in place of
+ * the seven lowest mantissa bits. Dropping those bits lowers a positive parameter (it is a lower bound anyway) and leaves a
+ * negative one negative; the parameter is only ever compared with the ray's threshold, which is never negative. One 8-byte
+ * LDS store per pushed leaf. */
+#define RT_LEAF_FIRST_MASK 0x01FFFFFFu
+static_assert(RT_RAY_SLOTS <= 128 && RT_NODE_BITS == 25, "leaf items: seven bits for the ray slot, 25 for the first primitive");
+__device__ __forceinline__ uint32_t leaf_word(float t, uint32_t slot) { return (__float_as_uint(t) & ~0x7Fu) | slot; }
+__device__ __forceinline__ uint2 leaf_item(uint32_t first, uint32_t count, float t, uint32_t slot) { return make_uint2(first | ((count - 1u) << 28), leaf_word(t, slot)); }
+__device__ __forceinline__ uint32_t leaf_first(uint2 it) { return it.x & RT_LEAF_FIRST_MASK; }
+__device__ __forceinline__ int leaf_count(uint2 it) { return (int)((it.x >> 28) & 7u) + 1; }
+__device__ __forceinline__ int leaf_slot(uint2 it) { return (int)(it.y & 0x7Fu); }
+__device__ __forceinline__ float leaf_entry(uint2 it) { return __uint_as_float(it.y & ~0x7Fu); }
+
 /* One record of the filter tree for ray slot rl: a child is pushed unless the ray certainly misses its box (box_fast_f's
  * miss; the filter's boxes are rounded outwards) or the box starts beyond the ray's threshold. Called by all 64 lanes;
  * lanes with have == false only take part in the prefix sum. item_t is the entry parameter the record was pushed with. */
@@ -719,10 +732,7 @@ __device__ __forceinline__ void wide_children(const DScene &sc, WaveLDS *w, int 
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             if (__builtin_amdgcn_inverse_ballot_w64(mn[c])) w->node[jn[c]] = make_uint2(code[c] | ((uint32_t)rl << RT_NODE_BITS), __float_as_uint(f[c]));
-            if (__builtin_amdgcn_inverse_ballot_w64(ml[c])) {
-                w->leaf[jl[c]] = make_uint2(code[c] & 0x0FFFFFFFu, (((code[c] >> 28) & 7u) + 1u) | ((uint32_t)rl << RT_NODE_BITS));
-                w->leaf_t[jl[c]] = f[c];
-            }
+            if (__builtin_amdgcn_inverse_ballot_w64(ml[c])) w->leaf[jl[c]] = make_uint2(code[c], leaf_word(f[c], (uint32_t)rl));
         }
         n_nodes = tn;
         n_leaves = tl;
@@ -798,13 +808,11 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
                 } else { /* the root is itself a leaf */
                     if (pa) {
                         const int qi = n_leaves + rank_in(ba);
-                        w->leaf[qi] = make_uint2((uint32_t)m.root, (uint32_t)m.root_count | ((uint32_t)lane << RT_NODE_BITS));
-                        w->leaf_t[qi] = fa;
+                        w->leaf[qi] = leaf_item((uint32_t)m.root, (uint32_t)m.root_count, fa, (uint32_t)lane);
                     }
                     if (pb) {
                         const int qi = n_leaves + ca + rank_in(bb);
-                        w->leaf[qi] = make_uint2((uint32_t)m.root, (uint32_t)m.root_count | ((uint32_t)(RT_WAVE + lane) << RT_NODE_BITS));
-                        w->leaf_t[qi] = fb;
+                        w->leaf[qi] = leaf_item((uint32_t)m.root, (uint32_t)m.root_count, fb, (uint32_t)(RT_WAVE + lane));
                     }
                     n_leaves = uni(n_leaves + ca + __popcll(bb));
                 }
@@ -837,8 +845,8 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
                 const bool quad = RT_LEAF_QUAD && !SPHP && (own ? RT_OWN_LEAF : RT_EXT_LEAF) <= RT_LEAF_QUAD;
                 if (!quad && lane < m) {
                     it = w->leaf[n_leaves - 1 - lane];
-                    cntl = (int)(it.y & RT_LOW_MASK);
-                    if (w->leaf_t[n_leaves - 1 - lane] > w->thrf[it.y >> RT_NODE_BITS]) cntl = 0;
+                    cntl = leaf_count(it);
+                    if (leaf_entry(it) > w->thrf[leaf_slot(it)]) cntl = 0;
                 }
                 bool have;
                 uint32_t tri;
@@ -851,15 +859,15 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
                     int cq = 0;
                     if (iq < mq) {
                         itq = w->leaf[n_leaves - 1 - iq];
-                        cq = (int)(itq.y & RT_LOW_MASK);
-                        if (w->leaf_t[n_leaves - 1 - iq] > w->thrf[itq.y >> RT_NODE_BITS]) cq = 0;
+                        cq = leaf_count(itq);
+                        if (leaf_entry(itq) > w->thrf[leaf_slot(itq)]) cq = 0;
                     }
 #ifdef RT_DIAG_STALE
                     if (CNT && !SPHP) { cnt.dbg[3] += __popcll(__ballot(iq < mq && rq == 0)); cnt.dbg[2] += __popcll(__ballot(iq < mq && rq == 0 && cq == 0)); }
 #endif
                     have = rq < cq;
-                    tri = itq.x + (uint32_t)rq;
-                    rl = (int)(itq.y >> RT_NODE_BITS);
+                    tri = leaf_first(itq) + (uint32_t)rq;
+                    rl = leaf_slot(itq);
                     take = mq << quad_shift;
                     n_leaves -= mq;
                 } else
@@ -867,8 +875,8 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
                 if ((SPHP ? RT_SPH_LEAF : RT_OWN_LEAF) == 1 && own) {
                     /* every leaf of the filter trees is one primitive: an item is a slot, nothing to spread out */
                     have = cntl > 0;
-                    tri = it.x;
-                    rl = (int)(it.y >> RT_NODE_BITS);
+                    tri = leaf_first(it);
+                    rl = leaf_slot(it);
                     take = m;
                     n_leaves -= m;
                 } else {
@@ -886,12 +894,12 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
                 uint2 itj = make_uint2(0u, 0u);
                 int exj = 0;
                 if (have) { itj = w->leaf[n_leaves - 1 - j]; exj = w->ex[j]; }
-                tri = itj.x + (uint32_t)(lane - exj);
-                rl = (int)(itj.y >> RT_NODE_BITS);
+                tri = leaf_first(itj) + (uint32_t)(lane - exj);
+                rl = leaf_slot(itj);
                 wave_sync();
                 if (lane < m && excl < RT_WAVE && incl > RT_WAVE) { /* the item cut by the last slot */
                     const uint32_t used = (uint32_t)(RT_WAVE - excl);
-                    w->leaf[n_leaves - 1 - lane] = make_uint2(it.x + used, ((uint32_t)cntl - used) | (it.y & ~RT_LOW_MASK));
+                    w->leaf[n_leaves - 1 - lane] = make_uint2((leaf_first(it) + used) | (((uint32_t)cntl - used - 1u) << 28), it.y);
                 }
                 n_leaves = uni(n_leaves - __popcll(__ballot(lane < m && incl <= RT_WAVE)));
                 }
@@ -1082,13 +1090,11 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
                 const int c2 = __popcll(b2);
                 if (pll) {
                     const int q = n_leaves + rank_in(b2);
-                    w->leaf[q] = make_uint2((uint32_t)L, (uint32_t)nL | ((uint32_t)rl << RT_NODE_BITS));
-                    w->leaf_t[q] = fl;
+                    w->leaf[q] = leaf_item((uint32_t)L, (uint32_t)nL, fl, (uint32_t)rl);
                 }
                 if (plr) {
                     const int q = n_leaves + c2 + rank_in(b3);
-                    w->leaf[q] = make_uint2((uint32_t)R, (uint32_t)nR | ((uint32_t)rl << RT_NODE_BITS));
-                    w->leaf_t[q] = fr;
+                    w->leaf[q] = leaf_item((uint32_t)R, (uint32_t)nR, fr, (uint32_t)rl);
                 }
                 n_leaves = uni(n_leaves + c2 + __popcll(b3));
                 wave_sync();

@@ -15,3 +15,4 @@ l=[x for x in open("gpurun_out/ab/%s.log"%sys.argv[1]) if x.startswith("{")][-1]
 print(sys.argv[1], d["value"], "Mpaths/s", d["roofline"]["avg_launch_ms"], "ms/launch")
 PY
 done
+cp /tmp/base.so $L
