@@ -530,6 +530,7 @@ __device__ __forceinline__ void hit_none(HitRec &h) {
 /* the margins of the sphere tree's boxes hold for rays that start within DScene::sph_reach of the coordinate origin */
 __device__ __forceinline__ bool sphere_walk_ok(const DScene &sc, V3 C) { return fabs(C.x) < sc.sph_reach && fabs(C.y) < sc.sph_reach && fabs(C.z) < sc.sph_reach; }
 
+__device__ __forceinline__ void ray_tables(const DScene &sc, WaveLDS *w, int slot, const RayQ &q, bool prune, const HitRec &h);
 /* Spheres for one ray and the ray's entry in the pool's tables. */
 template <bool CNT, bool SPH, typename SP>
 __device__ __forceinline__ void ray_begin(const DScene &sc, WaveLDS *w, SP sph, int slot, const RayQ &q, bool prune, bool spheres_done,
@@ -545,7 +546,49 @@ __device__ __forceinline__ void ray_begin(const DScene &sc, WaveLDS *w, SP sph, 
         for (int s = 0; s < n_sph; s++) sphere_test_counted(sph, s, C, u, h);
     }
     if (CNT) { cnt.sph_tests += (uint64_t)h.sph_tests; cnt.sph_nodes += (uint64_t)h.sph_nodes; }
-    if (sc.n_meshes == 0) return;
+    ray_tables(sc, w, slot, q, prune, h);
+}
+
+/* Sphere::intersect and Scene::intersect's choice (sphere_test above) for a lane's two rays at once and without branches:
+ * the two chains of dependent instructions (square root, divisions) do not depend on each other and are issued
+ * interleaved, and the sphere is read once. A ray that is not active, a negative discriminant (its root is then a NaN) and
+ * t2 < 0 all end in "no update", as the early returns of the reference do. */
+template <typename SP>
+__device__ __forceinline__ void sphere_test2(SP sph, int s, const RayQ &qa, const RayQ &qb, HitRec &ha, HitRec &hb) {
+    const V3 O = ld3(sph[s].O);
+    const double R = sph[s].R;
+    const int32_t oid = sph[s].object_id;
+    const double a = 1;
+    const RayQ *const q[2] = {&qa, &qb};
+    HitRec *const h[2] = {&ha, &hb};
+    double t[2];
+    bool hit[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const V3 CO = sub(q[r]->C, O);
+        const double b = 2 * dot(q[r]->u, CO);
+        const double c = norm2(CO) - R * R;
+        const double delta = b * b - 4 * a * c;
+        const double sq = sqrt(delta);
+        const double t2 = (-b + sq) / (2 * a);
+        const double t1 = (-b - sq) / (2 * a);
+        t[r] = (t1 > 0) ? t1 : t2;
+        hit[r] = q[r]->active & !(delta < 0) & !(t2 < 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const bool upd = hit[r] & ((t[r] < h[r]->t) | ((t[r] == h[r]->t) & (oid < h[r]->obj)));
+        h[r]->t = upd ? t[r] : h[r]->t;
+        h[r]->obj = upd ? oid : h[r]->obj;
+        h[r]->prim = upd ? s : h[r]->prim;
+        h[r]->mesh = upd ? -1 : h[r]->mesh;
+    }
+}
+
+/* The pool's table entries of one ray once its closest sphere is known (h). */
+__device__ __forceinline__ void ray_tables(const DScene &sc, WaveLDS *w, int slot, const RayQ &q, bool prune, const HitRec &h) {
+    if (!q.active || sc.n_meshes == 0) return;
+    const V3 C = q.C, u = q.u;
     /* Mesh hits are accepted only below t0 = min(1E9, sphere hit, tmax): TriangleMesh::intersect starts at
      * t = 1E9 (raytracer.cpp:647), a mesh hit beyond the closest sphere loses in Scene::intersect (:938)
      * and one beyond tmax cannot matter to the caller. A mesh hit AT t0 is still recorded (tie rules). */
@@ -567,6 +610,23 @@ __device__ __forceinline__ void ray_begin(const DScene &sc, WaveLDS *w, SP sph, 
     /* While nothing closer than 1E9 is known, nothing may be skipped by distance: a triangle hit at or beyond
      * 1E9 still makes TriangleMesh::intersect return true (raytracer.cpp:689 sets has_inter before :690 compares). */
     w->thrf[slot] = (prune && t0 < 1E9) ? upper_float(t0 * RT_PRUNE_SLACK) : __builtin_huge_valf();
+}
+
+/* ray_begin for both rays of a lane where the sphere list is short (every sphere is tested for every ray) */
+template <bool CNT, typename SP>
+__device__ __forceinline__ void rays_begin2(const DScene &sc, WaveLDS *w, SP sph, int lane, const RayQ &qa, const RayQ &qb, bool prune, HitRec &ha, HitRec &hb,
+                                            Cnt &cnt) {
+    hit_none(ha);
+    hit_none(hb);
+    const int n_sph = uni(sc.n_spheres); /* wave-uniform also when read from LDS */
+    for (int s = 0; s < n_sph; s++) sphere_test2(sph, s, qa, qb, ha, hb);
+    if (CNT) {
+        const uint64_t n = (uint64_t)(qa.active ? 1 : 0) + (uint64_t)(qb.active ? 1 : 0);
+        cnt.rays += n;
+        cnt.sph_tests += n * (uint64_t)n_sph;
+    }
+    ray_tables(sc, w, lane, qa, prune, ha);
+    ray_tables(sc, w, RT_WAVE + lane, qb, prune, hb);
 }
 
 /* The mesh hits of a lane's two rays, and Scene::intersect's choice between each and the sphere hit. After a
@@ -1197,8 +1257,12 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScen
   for (;;) {
     bool sa = false, sb = false;
     if (SPH && cold.sph_rec4 != nullptr && prune) spheres_pool<CNT>(sc, cold, w, sph, qa, qb, ha, hb, sa, sb, cnt, st0);
-    ray_begin<CNT, SPH>(cold, w, sph, lane, qa, prune, sa, ha, cnt);
-    ray_begin<CNT, SPH>(cold, w, sph, RT_WAVE + lane, qb, prune, sb, hb, cnt);
+    if (SPH) {
+        ray_begin<CNT, SPH>(cold, w, sph, lane, qa, prune, sa, ha, cnt);
+        ray_begin<CNT, SPH>(cold, w, sph, RT_WAVE + lane, qb, prune, sb, hb, cnt);
+    } else {
+        rays_begin2<CNT>(cold, w, sph, lane, qa, qb, prune, ha, hb, cnt);
+    }
     if (CNT) { const uint64_t t = RT_STAMP(); cnt.cyc_roots += t - st0; st0 = t; } /* spheres and ray constants count with the roots */
     if (sc.n_meshes == 0) return;
     {
