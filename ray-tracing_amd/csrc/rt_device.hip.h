@@ -45,6 +45,14 @@
 namespace rtd {
 __device__ __noinline__ double2 dev_sincos(double x) { double s, c; rtm::sincos_0_7(x, &s, &c); return make_double2(s, c); }
 __device__ __noinline__ double dev_log(double x) { return rtm::log_pos(x); }
+/* two at once: the evaluations do not depend on each other and their instructions are issued interleaved */
+__device__ __noinline__ double4 dev_sincos2(double x, double y) {
+    double s, c, s2, c2;
+    rtm::sincos_0_7(x, &s, &c);
+    rtm::sincos_0_7(y, &s2, &c2);
+    return make_double4(s, c, s2, c2);
+}
+__device__ __noinline__ double2 dev_log2(double x, double y) { return make_double2(rtm::log_pos(x), rtm::log_pos(y)); }
 }
 #define RT_SINCOS(arg_, ps_, pc_) do { const double2 sc_ = rtd::dev_sincos(arg_); *(ps_) = sc_.x; *(pc_) = sc_.y; } while (0)
 #define RT_LOG(arg_) rtd::dev_log(arg_)
@@ -1347,10 +1355,9 @@ __device__ __forceinline__ void hit_surface(const DScene &sc, SP sph, V3 C, V3 u
     }
 }
 
-/* random_cos, raytracer.cpp:112-138 */
-__device__ __forceinline__ V3 random_cos(double u1, double u2, V3 N) {
-    double sn, cs; /* rt_math.h: the same bits as the CPU checker computes with the same function */
-    RT_SINCOS(2 * RT_PI * u1, &sn, &cs);
+/* random_cos, raytracer.cpp:112-138; sn, cs = sin and cos of 2 pi u1 (rt_math.h: the same bits as the CPU checker computes
+ * with the same function) */
+__device__ __forceinline__ V3 random_cos_sc(double sn, double cs, double u2, V3 N) {
     double x = cs * sqrt(1 - u2);
     double y = sn * sqrt(1 - u2);
     double z = sqrt(u2);
@@ -1361,6 +1368,11 @@ __device__ __forceinline__ V3 random_cos(double u1, double u2, V3 N) {
     T1 = unit(T1);
     V3 T2 = cross(N, T1);
     return add(add(smul(z, N), smul(x, T1)), smul(y, T2));
+}
+__device__ __forceinline__ V3 random_cos(double u1, double u2, V3 N) {
+    double sn, cs;
+    RT_SINCOS(2 * RT_PI * u1, &sn, &cs);
+    return random_cos_sc(sn, cs, u2, N);
 }
 
 /* State of one pixel's sample loop between two queries: the rays to trace next and what the recursion of
@@ -1412,14 +1424,12 @@ __device__ __forceinline__ void path_fresh(const RenderArgs &ra, Path &q, int i,
         q.ru = dir;
     } else { /* raytracer.cpp:1467-1483 */
         double u1 = rng_uniform(q.key, 0), u2 = rng_uniform(q.key, 1);
-        double s1, c1, s3, c3;
-        RT_SINCOS(2 * RT_PI * u1, &s1, &c1);
-        const double l2 = RT_LOG(u2);
+        double u3 = rng_uniform(q.key, 2), u4 = rng_uniform(q.key, 3);
+        const double4 sc13 = dev_sincos2(2 * RT_PI * u1, 2 * RT_PI * u3);
+        const double2 l24 = dev_log2(u2, u4);
+        const double s1 = sc13.x, c1 = sc13.y, s3 = sc13.z, c3 = sc13.w, l2 = l24.x, l4 = l24.y;
         double x1 = cam.aa_sigma * c1 * sqrt(-2 * l2),
                x2 = cam.aa_sigma * s1 * sqrt(-2 * l2);
-        double u3 = rng_uniform(q.key, 2), u4 = rng_uniform(q.key, 3);
-        RT_SINCOS(2 * RT_PI * u3, &s3, &c3);
-        const double l4 = RT_LOG(u4);
         double x3 = cam.dof_sigma * c3 * sqrt(-2 * l4),
                x4 = cam.dof_sigma * s3 * sqrt(-2 * l4);
         q.ctr = 4;
@@ -1531,7 +1541,22 @@ __device__ __forceinline__ void path_advance(const DScene &sc, SP sph, const Ren
             branch = RT_TRACE_DIFFUSE_LIT; /* until the shadow ray's answer says otherwise */
             const V3 Lpos = ld3(sc.L);
             V3 shC = add(P, smul(0.00001, N)), shU;
-            if (fl & RT_F_POINT_LIGHT) { /* :1040-1055 */
+            /* The draws of the vertex in the reference's order - two for the light sample (:1062), then two for the indirect
+             * ray (:1087) - and the sine / cosine pairs of both directions from one call when both are needed. */
+            const bool area = !(fl & RT_F_POINT_LIGHT);
+            const bool indirect = !(fl & RT_F_NO_INDIRECT) && !(lean && q.rebond >= p.max_rebond);
+            double uL1 = 0, uL2 = 0, uI1 = 0, uI2 = 0, sL = 0, cL = 0, sI = 0, cI = 0;
+            if (area) { uL1 = rng_uniform(q.key, q.ctr); uL2 = rng_uniform(q.key, q.ctr + 1); q.ctr += 2; }
+            if (indirect) { uI1 = rng_uniform(q.key, q.ctr); uI2 = rng_uniform(q.key, q.ctr + 1); q.ctr += 2; }
+            if (area && indirect) {
+                const double4 r4 = dev_sincos2(2 * RT_PI * uL1, 2 * RT_PI * uI1);
+                sL = r4.x; cL = r4.y; sI = r4.z; cI = r4.w;
+            } else if (area) {
+                RT_SINCOS(2 * RT_PI * uL1, &sL, &cL);
+            } else if (indirect) {
+                RT_SINCOS(2 * RT_PI * uI1, &sI, &cI);
+            }
+            if (!area) { /* :1040-1055 */
                 V3 PL = sub(Lpos, P);
                 double d = sqrt(norm2(PL));
                 shU = divs(PL, d);
@@ -1541,9 +1566,7 @@ __device__ __forceinline__ void path_advance(const DScene &sc, SP sph, const Ren
                 const V3 lightO = ld3(sc.lightO);
                 const double lightR = sc.lightR;
                 V3 PL = unit(sub(Lpos, P));
-                double u1 = rng_uniform(q.key, q.ctr), u2 = rng_uniform(q.key, q.ctr + 1);
-                q.ctr += 2;
-                V3 wv = random_cos(u1, u2, neg(PL));
+                V3 wv = random_cos_sc(sL, cL, uL2, neg(PL));
                 V3 xprime = add(muls(wv, lightR), lightO);
                 V3 Px = sub(xprime, P);
                 double d = sqrt(norm2(Px));
@@ -1556,10 +1579,8 @@ __device__ __forceinline__ void path_advance(const DScene &sc, SP sph, const Ren
                 q.sh_limit = d - p.shadow_bias;
             }
             if (lean && q.nee.x == 0 && q.nee.y == 0 && q.nee.z == 0) q.sh_limit = 0;
-            if (!(fl & RT_F_NO_INDIRECT) && !(lean && q.rebond >= p.max_rebond)) { /* :1086-1087; its two draws follow the light's two */
-                double u1 = rng_uniform(q.key, q.ctr), u2 = rng_uniform(q.key, q.ctr + 1);
-                q.ctr += 2;
-                q.ru = random_cos(u1, u2, N);
+            if (indirect) { /* :1086-1087 */
+                q.ru = random_cos_sc(sI, cI, uI2, N);
                 q.rC = add(P, smul(epsilon, N));
                 q.vAlbedo = s.albedo;
             } else {

@@ -42,11 +42,11 @@ RTM_FN double from_bits(uint64_t u) {
  * n * (first piece) is exact and so is its subtraction from x (both within a factor of two), the second and third
  * pieces give r as a head r0 and a tail r1 with an error below 1e-36. Then the Taylor polynomials on |r| <= pi/4 up to
  * r^17 (sine) and r^18 (cosine): truncation below 2^-60 relative. */
-RTM_FN void sincos_0_7(double x, double *sn, double *cs) {
-    if (!(x >= 0.0 && x < 7.0)) {
-        *sn = *cs = __builtin_nan("");
-        return;
-    }
+RTM_FN void sincos_0_7(double x_in, double *sn, double *cs) {
+    /* no branches (an argument outside the range is computed as 0 and replaced at the end): two calls in a row are then
+     * one straight piece of code whose two chains of dependent operations the compiler can issue interleaved */
+    const bool bad = !(x_in >= 0.0 && x_in < 7.0);
+    const double x = bad ? 0.0 : x_in;
     const int n = (int)(x * 0.63661977236758138243 + 0.5); /* x * 2/pi is below 4.46 */
     const double fn = (double)n;
     const double p1 = 1.57079632673412561417e+00;  /* 0x3FF921FB54400000: the first 33 bits of pi/2 */
@@ -86,8 +86,10 @@ RTM_FN void sincos_0_7(double x, double *sn, double *cs) {
     const int q = n & 3;
     const double s_out = (q & 1) ? cr : sr;
     const double c_out = (q & 1) ? sr : cr;
-    *sn = (q & 2) ? -s_out : s_out;
-    *cs = (q == 1 || q == 2) ? -c_out : c_out;
+    const double s_fin = (q & 2) ? -s_out : s_out;
+    const double c_fin = (q == 1 || q == 2) ? -c_out : c_out;
+    *sn = bad ? __builtin_nan("") : s_fin;
+    *cs = bad ? __builtin_nan("") : c_fin;
 }
 
 /* Natural logarithm of a positive normal double (the callers pass a uniform draw u = k 2^-53 in [0, 1)). log(+0) and
@@ -99,16 +101,14 @@ RTM_FN void sincos_0_7(double x, double *sn, double *cs) {
  * log m = f - (f^2/2 - s (f^2/2 + R)), which keeps the division's rounding error out of the leading term; e log 2 is added
  * in two pieces, the first with 11 trailing zero bits so that e * (first piece) is exact. */
 RTM_FN double log_pos(double x) {
+    /* no branches, for the same reason as above: the special arguments are replaced at the end */
     const uint64_t bx = bits_of(x);
-    if ((bx << 1) == 0) return -__builtin_huge_val();
-    if ((bx >> 63) || x != x) return __builtin_nan("");
-    if (bx == 0x7FF0000000000000ull) return x;
-    int e = (int)(bx >> 52) - 1023;
-    double m = from_bits((bx & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull); /* [1, 2) */
-    if (m > 1.41421356237309514547) {
-        m *= 0.5;
-        e += 1;
-    }
+    const bool is_zero = (bx << 1) == 0, is_nan = (bx >> 63) || x != x, is_inf = bx == 0x7FF0000000000000ull;
+    const int e0 = (int)((bx >> 52) & 0x7FF) - 1023;
+    const double m0 = from_bits((bx & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull); /* [1, 2) */
+    const bool upper = m0 > 1.41421356237309514547;
+    const double m = upper ? m0 * 0.5 : m0;
+    const int e = upper ? e0 + 1 : e0;
     const double f = m - 1.0;
     const double s = f / (2.0 + f);
     const double z = s * s;
@@ -126,7 +126,8 @@ RTM_FN double log_pos(double x) {
     const double hfsq = 0.5 * f * f;
     const double dk = (double)e;
     const double ln2_hi = 0.6931471805598903 /* 0x1.62e42fefa3800p-1 */, ln2_lo = 5.497923018708371e-14 /* 0x1.ef35793c76730p-45 */;
-    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+    const double r = dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+    return is_zero ? -__builtin_huge_val() : (is_nan ? __builtin_nan("") : (is_inf ? x : r));
 }
 
 } /* namespace rtm */
