@@ -749,8 +749,8 @@ __device__ __forceinline__ float leaf_entry(uint2 it) { return __uint_as_float(i
 
 /* One record of the filter tree for ray slot rl: a child is pushed unless the ray certainly misses its box (box_fast_f's
  * miss; the filter's boxes are rounded outwards) or the box starts beyond the ray's threshold. Called by all 64 lanes;
- * lanes with have == false only take part in the prefix sum. item_t is the entry parameter the record was pushed with. */
-__device__ __forceinline__ void wide_children(const DScene &sc, WaveLDS *w, int lane, bool have, int rl, float item_t, const float4 &q0, const float4 &q1,
+ * have_mask: the lanes that hold a record. item_t is the entry parameter the record was pushed with. */
+__device__ __forceinline__ void wide_children(const DScene &sc, WaveLDS *w, int lane, unsigned long long have_mask, int rl, float item_t, const float4 &q0, const float4 &q1,
                                               const float4 &q2, const float4 &q3, const float4 &q4, const float4 &q5, const uint4 &ch, int &n_nodes, int &n_leaves) {
     const float thrf = w->thrf[rl];
     const float iux = w->rayf[0][rl], iuy = w->rayf[1][rl], iuz = w->rayf[2][rl];
@@ -759,7 +759,7 @@ __device__ __forceinline__ void wide_children(const DScene &sc, WaveLDS *w, int 
     /* The lanes' yes/no answers are kept as wave masks (one compare each, combined by scalar instructions) and turned back
      * into lane predicates only where something is stored: the ballot of a combined lane condition costs two vector
      * instructions more than the ballot of a plain compare. */
-    const unsigned long long bh = wave_ballot(have) & wave_ballot(!(item_t > thrf)); /* not fallen behind the threshold since it was pushed */
+    const unsigned long long bh = have_mask & wave_ballot(!(item_t > thrf)); /* not fallen behind the threshold since it was pushed */
     const float bx[24] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w,
                           q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w};
     const uint32_t code[4] = {ch.x, ch.y, ch.z, ch.w};
@@ -846,11 +846,11 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
             const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3], q4 = rp[4], q5 = rp[5];
             const uint4 ch = *reinterpret_cast<const uint4 *>(rp + 6);
             const float ninf = -__builtin_huge_valf();
-            wide_children(sc, w, lane, act_a, lane, ninf, q0, q1, q2, q3, q4, q5, ch, n_nodes, n_leaves);
+            wide_children(sc, w, lane, mask_a, lane, ninf, q0, q1, q2, q3, q4, q5, ch, n_nodes, n_leaves);
             const unsigned long long bb = __ballot(act_b);
             const int nb = __popcll(bb);
             if (n_nodes + 4 * nb <= node_soft && n_leaves + 4 * nb <= RT_LEAF_CAP) {
-                wide_children(sc, w, lane, act_b, RT_WAVE + lane, ninf, q0, q1, q2, q3, q4, q5, ch, n_nodes, n_leaves);
+                wide_children(sc, w, lane, mask_b, RT_WAVE + lane, ninf, q0, q1, q2, q3, q4, q5, ch, n_nodes, n_leaves);
             } else {
                 if (act_b) w->node[n_nodes + rank_in(bb)] = make_uint2((uint32_t)(RT_WAVE + lane) << RT_NODE_BITS, __float_as_uint(ninf));
                 n_nodes += nb;
@@ -975,9 +975,11 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
                 bool acc = false;
                 double beta, gamma, lt = 0;
                 bool ok = have;
-                if (have && tri >= n_tri_lim) { /* never fetch outside the arrays */
-                    atomicOr(sc.overflow, 2);
-                    ok = false;
+                if (__builtin_expect(wave_ballot(have && tri >= n_tri_lim) != 0ull, 0)) { /* never fetch outside the arrays */
+                    if (have && tri >= n_tri_lim) {
+                        atomicOr(sc.overflow, 2);
+                        ok = false;
+                    }
                 }
                 /* all coordinate loads and the ray's LDS reads are issued before anything is waited for:
                  * unconditional (a lane without a triangle reads triangle 0), fenced, then pinned */
@@ -1062,17 +1064,21 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
                 int k = n_nodes < RT_WAVE ? n_nodes : RT_WAVE;
                 const int room = (node_soft - n_nodes) / 3;
                 if (k > room) k = room > 1 ? room : 1;
-                bool have = lane < k;
-                const uint2 it = w->node[have ? n_nodes - 1 - lane : 0];
+                const unsigned long long in_k = wave_ballot(lane < k);
+                const uint2 it = w->node[__builtin_amdgcn_inverse_ballot_w64(in_k) ? n_nodes - 1 - lane : 0];
                 n_nodes -= k;
                 wave_sync();
                 const int rl = (int)(it.x >> RT_NODE_BITS);
                 uint32_t rec = it.x & RT_LOW_MASK;
                 if (CNT && RT_STAMP_STEPS) { asm volatile("" :: "v"(rec)); const uint64_t t = RT_STAMP(); cnt.dbg[0] += t - st0; st0 = t; } /* the item has arrived */
-                if (have && rec >= n_recs) { /* never fetch outside the arrays */
-                    have = false;
-                    atomicOr(sc.overflow, 2);
+                /* never fetch outside the arrays: the lanes' answers as one mask, so that the step has no branch that is
+                 * taken unless something is wrong */
+                const unsigned long long outside = in_k & wave_ballot(rec >= n_recs);
+                if (__builtin_expect(outside != 0ull, 0)) {
+                    if (lane == 0) atomicOr(sc.overflow, 2);
                 }
+                const unsigned long long have_mask = in_k & ~outside;
+                const bool have = __builtin_amdgcn_inverse_ballot_w64(have_mask);
                 if (!have) rec = 0;
                 if (CNT && SPHP && have) cnt.sph_nodes += 4; /* four box tests per record */
                 const float4 *rp = reinterpret_cast<const float4 *>(tree4 + rec);
@@ -1085,7 +1091,7 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
 #ifdef RT_DIAG_STALE /* diagnostic: popped node items / those that had fallen behind their ray's threshold */
                 if (CNT && !SPHP) { cnt.dbg[1] += __popcll(__ballot(have)); cnt.dbg[0] += __popcll(__ballot(have && __uint_as_float(it.y) > w->thrf[rl])); }
 #endif
-                wide_children(sc, w, lane, have, rl, __uint_as_float(it.y), q0, q1, q2, q3, q4, q5, ch, n_nodes, n_leaves);
+                wide_children(sc, w, lane, have_mask, rl, __uint_as_float(it.y), q0, q1, q2, q3, q4, q5, ch, n_nodes, n_leaves);
                 wave_sync();
                 if (CNT) {
                     uint64_t t = RT_STAMP();
