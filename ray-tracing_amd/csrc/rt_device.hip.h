@@ -1321,21 +1321,24 @@ struct Surf {
 /* what Scene::intersect hands back for the winning object: P, N, colour, material */
 template <typename SP>
 __device__ __forceinline__ void hit_surface(const DScene &sc, SP sph, V3 C, V3 u, const HitRec &h, Surf &s) {
+    /* the normal before normalisation: get_normalized (a square root and three divisions) is then one piece of code
+     * for sphere and mesh hits instead of one in each branch, which a wave with both kinds of lanes would run twice */
+    V3 nraw = mk(0, 0, 0);
     if (h.mesh < 0) { /* Sphere::intersect :914-915 */
         V3 O = ld3(sph[h.prim].O);
         s.P = add(C, smul(h.t, u));
-        s.N = unit(sub(s.P, O));
+        nraw = sub(s.P, O);
         s.albedo = ld3(sph[h.prim].albedo);
         s.flags = sph[h.prim].flags;
     } else if (h.prim < 0) { /* a mesh hit without a triangle: Scene::intersect's zero-initialised locals (:936) */
-        s.P = s.N = s.albedo = mk(0, 0, 0);
+        s.P = s.albedo = mk(0, 0, 0);
         s.flags = in_global(sc.meshes)[h.mesh].flags;
     } else { /* TriangleMesh::intersect :693-720 */
         const rt_mesh &m = in_global(sc.meshes)[h.mesh];
         const rt_tri_attr *at = in_global(sc.attrs) + h.prim;
         double beta = h.beta, gamma = h.gamma, alpha = 1 - beta - gamma;
         V3 nn = add(add(smul(alpha, ld3(at->n[0])), smul(beta, ld3(at->n[1]))), smul(gamma, ld3(at->n[2])));
-        s.N = unit(nn);
+        nraw = nn;
         s.P = add(C, u); /* raytracer.cpp:696: C + u, not C + t u */
         s.flags = m.flags;
         if (m.n_tex > 0) {
@@ -1359,6 +1362,8 @@ __device__ __forceinline__ void hit_surface(const DScene &sc, SP sph, V3 C, V3 u
             s.albedo = ld3(m.albedo);
         }
     }
+    const V3 nunit = unit(nraw);
+    s.N = (h.mesh >= 0 && h.prim < 0) ? mk(0, 0, 0) : nunit;
 }
 
 /* random_cos, raytracer.cpp:112-138; sn, cs = sin and cos of 2 pi u1 (rt_math.h: the same bits as the CPU checker computes
