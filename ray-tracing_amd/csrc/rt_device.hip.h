@@ -1557,14 +1557,15 @@ __device__ __forceinline__ void path_advance(const DScene &sc, SP sph, const Ren
             const bool area = !(fl & RT_F_POINT_LIGHT);
             const bool indirect = !(fl & RT_F_NO_INDIRECT) && !(lean && q.rebond >= p.max_rebond);
             double uL1 = 0, uL2 = 0, uI1 = 0, uI2 = 0, sL = 0, cL = 0, sI = 0, cI = 0;
+            /* The indirect ray is made whether or not it will be traced (a sample that does not trace it ends at this vertex
+             * and draws nothing more): no branch then separates its arithmetic from the light sample's, and the two
+             * directions - a square root and three divisions each - are issued interleaved. */
             if (area) { uL1 = rng_uniform(q.key, q.ctr); uL2 = rng_uniform(q.key, q.ctr + 1); q.ctr += 2; }
-            if (indirect) { uI1 = rng_uniform(q.key, q.ctr); uI2 = rng_uniform(q.key, q.ctr + 1); q.ctr += 2; }
-            if (area && indirect) {
+            uI1 = rng_uniform(q.key, q.ctr); uI2 = rng_uniform(q.key, q.ctr + 1); q.ctr += 2;
+            if (area) {
                 const double4 r4 = dev_sincos2(2 * RT_PI * uL1, 2 * RT_PI * uI1);
                 sL = r4.x; cL = r4.y; sI = r4.z; cI = r4.w;
-            } else if (area) {
-                RT_SINCOS(2 * RT_PI * uL1, &sL, &cL);
-            } else if (indirect) {
+            } else {
                 RT_SINCOS(2 * RT_PI * uI1, &sI, &cI);
             }
             if (!area) { /* :1040-1055 */
@@ -1590,13 +1591,11 @@ __device__ __forceinline__ void path_advance(const DScene &sc, SP sph, const Ren
                 q.sh_limit = d - p.shadow_bias;
             }
             if (lean && q.nee.x == 0 && q.nee.y == 0 && q.nee.z == 0) q.sh_limit = 0;
-            if (indirect) { /* :1086-1087 */
-                q.ru = random_cos_sc(sI, cI, uI2, N);
-                q.rC = add(P, smul(epsilon, N));
-                q.vAlbedo = s.albedo;
-            } else {
-                q.segment = false;
-            }
+            /* :1086-1087 */
+            q.ru = random_cos_sc(sI, cI, uI2, N);
+            q.rC = add(P, smul(epsilon, N));
+            q.vAlbedo = s.albedo;
+            q.segment = indirect;
             q.shC = shC;
             q.shU = shU;
             q.shadow = true;
