@@ -120,6 +120,13 @@ def _check(seed, gpu):
     ijk = np.array([(i, j, k) for i in range(W) for j in range(W) for k in range(3)], np.int32)
     g, tg = gpu.sample_trace(cam, p, ijk)
     c, tc = orc.sample_trace(cam, p, ijk)
+    # the same samples without the trace: rays whose answer cannot matter are then not traced at all (zero direct term,
+    # beyond the depth limit, shadow ray already blocked by a sphere); the value must keep every bit
+    lean = gpu.sample_radiance(cam, p, ijk)
+    if not np.array_equal(lean, g, equal_nan=True):
+        bad = np.nonzero((lean != g) & ~(np.isnan(lean) & np.isnan(g)))[0]
+        print("seed %d: %d samples differ between the traced and the untraced form; first: %s %s vs %s" % (seed, len(bad), ijk[bad[0]], lean[bad[0]], g[bad[0]]))
+        return False
     both_nan = np.isnan(g) & np.isnan(c)
     rel = np.abs(g - c) / np.maximum(np.abs(c), 1e-3)
     rel[both_nan] = 0
