@@ -1212,9 +1212,16 @@ __device__ __forceinline__ void spheres_pool(const DScene &sc, const DScene &col
     const unsigned long long mask_a = wave_ballot(done_a), mask_b = wave_ballot(done_b);
     if ((mask_a | mask_b) == 0ull) return;
     const int n_big = uni(cold.n_sph_big);
-    for (int s = 0; s < n_big; s++) {
-        if (done_a) sphere_test_counted(sph, s, qa.C, qa.u, ha);
-        if (done_b) sphere_test_counted(sph, s, qb.C, qb.u, hb);
+    if (CNT) {
+        for (int s = 0; s < n_big; s++) {
+            if (done_a) sphere_test_counted(sph, s, qa.C, qa.u, ha);
+            if (done_b) sphere_test_counted(sph, s, qb.C, qb.u, hb);
+        }
+    } else { /* both rays per sphere in one branch-free piece of code */
+        RayQ wa = qa, wb = qb;
+        wa.active = done_a;
+        wb.active = done_b;
+        for (int s = 0; s < n_big; s++) sphere_test2(sph, s, wa, wb, ha, hb);
     }
     const RayQ *const q[2] = {&qa, &qb};
     HitRec *const h[2] = {&ha, &hb};
