@@ -44,6 +44,9 @@ def _check_samples(gpu, orc, cam, p, ijk):
     assert (rel > 1e-9).sum() == 0, (int((rel > 1e-9).sum()), len(ijk), np.sort(rel)[-5:])
     diff = np.nonzero((tg != to).any(axis=(1, 2)))[0]
     assert len(diff) == 0, (len(diff), ijk[diff[0]], tg[diff[0]], to[diff[0]])
+    # without the trace the kernel leaves out the rays whose answer cannot matter (zero direct term, beyond the depth
+    # limit, shadow ray already blocked by a sphere): the value must keep every bit
+    assert np.array_equal(gpu.sample_radiance(cam, p, ijk), g, equal_nan=True)
     return rel
 
 
@@ -251,6 +254,26 @@ def test_stochastic_per_sample(gpu, rta, scenes, ob, name, kw):
     p = rta.make_params(W, W, 4, flags=flags)
     ijk = np.array([(i, j, k) for i in range(0, W, 2) for j in range(0, W, 2) for k in range(4)], np.int32)
     _check_samples(gpu, orc, cam, p, ijk)
+
+
+@pytest.mark.parametrize("max_rebond", [0, 1, 2, 5])
+@pytest.mark.parametrize("name,kw", [("sphere_room", dict(W=48)), ("mesh_room", dict(W=48, n_tris=5000, tex_size=64))])
+def test_depth_limit_and_rays_left_out(gpu, rta, scenes, ob, name, kw, max_rebond):
+    """short depth limits: the ray that leaves a vertex at the limit is intersected and dropped by the reference
+    (raytracer.cpp:960-963) and not traced here - diffuse, mirror and glass vertices alike; samples, paths and the
+    rendered accumulator against the oracle"""
+    s, cam, flags, orc = _scene_pair(ob, scenes, getattr(scenes, name), **kw)
+    gpu.upload(s)
+    W = kw["W"]
+    p = rta.make_params(W, W, 3, flags=flags)
+    p.max_rebond = max_rebond
+    ijk = np.array([(i, j, k) for i in range(W) for j in range(0, W, 2) for k in range(3)], np.int32)
+    _check_samples(gpu, orc, cam, p, ijk)
+    gpu.accum_clear(W, W)
+    gpu.render(cam, p)
+    g = gpu.accum_download(W, W)
+    o = orc.render(cam, p)
+    assert _rel_err(g.reshape(-1, 3), np.asarray(o).reshape(-1, 3)).max() < 1e-9
 
 
 @pytest.mark.parametrize("kind", ["light_only", "one_triangle", "coincident_triangles", "mesh_behind_camera"])
