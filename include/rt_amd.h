@@ -162,8 +162,12 @@ typedef struct rt_camera {
 #define RT_F_NO_FRESNEL 4u  /* dielectric always refracts unless total reflection (raytracer.cpp:1033) */
 #define RT_F_NO_JITTER 8u   /* camera ray Ray(C,u) through the pixel centre (raytracer.cpp:1482), no RNG draws */
 #define RT_F_COUNTERS 16u   /* accumulate rt_counters (slower) */
-#define RT_F_NO_PRUNE 32u   /* visit every BVH node whose box the ray's line crosses, as TriangleMesh::intersect does (raytracer.cpp:652-666);
-                               default: skip boxes that start behind the closest hit found so far (same results) */
+#define RT_F_NO_PRUNE 32u   /* trace every ray and visit every BVH node whose box the ray's line crosses, as Scene::getColor and
+                               TriangleMesh::intersect do (raytracer.cpp:953-1093, :652-666); default: skip boxes that start behind
+                               the closest hit found so far, end a shadow ray at its first hit before the light, and do not trace
+                               rays whose answer cannot change the sample - the shadow ray of a vertex whose direct term is exactly
+                               zero, the ray that leaves a vertex at depth max_rebond (intersected and then dropped, :960-963) -
+                               with bit-identical results */
 
 typedef struct rt_params {
     int32_t W, H;
@@ -180,7 +184,7 @@ typedef struct rt_params {
 
 typedef struct rt_counters {
     uint64_t paths;      /* camera samples = Scene::getColor(r,0,false) calls (raytracer.cpp:1485) */
-    uint64_t rays;       /* Scene::intersect calls (raytracer.cpp:930) */
+    uint64_t rays;       /* Scene::intersect calls (raytracer.cpp:930); without RT_F_NO_PRUNE: the rays actually traced (fewer) */
     uint64_t box_tests;  /* BoudingBox::intersect calls (raytracer.cpp:163) */
     uint64_t nodes;      /* BVH records popped (inner Noeuds visited) */
     uint64_t tris;       /* triangle tests (raytracer.cpp:670-687) */
