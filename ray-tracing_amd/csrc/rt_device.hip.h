@@ -103,6 +103,9 @@ namespace rtd {
 #define RT_TRAV_PRIO 1            /* issue priority of a wave while it is in the pool traversal, whose steps are chains of dependent
                                      instructions (elsewhere RT_SHADE_PRIO): 1, 2, 3 all +1.2 % on the battle scene; the reverse -0.7 % */
 #endif
+#ifndef RT_NARROW_STEP
+#define RT_NARROW_STEP 1          /* node steps with at most 32 records give each record two lanes */
+#endif
 #ifndef RT_SHADE_PRIO
 #define RT_SHADE_PRIO 0
 #endif
@@ -750,8 +753,11 @@ __device__ __forceinline__ float leaf_entry(uint2 it) { return __uint_as_float(i
 /* One record of the filter tree for ray slot rl: a child is pushed unless the ray certainly misses its box (box_fast_f's
  * miss; the filter's boxes are rounded outwards) or the box starts beyond the ray's threshold. Called by all 64 lanes;
  * have_mask: the lanes that hold a record. item_t is the entry parameter the record was pushed with. */
-__device__ __forceinline__ void wide_children(const DScene &sc, WaveLDS *w, int lane, unsigned long long have_mask, int rl, float item_t, const float4 &q0, const float4 &q1,
-                                              const float4 &q2, const float4 &q3, const float4 &q4, const float4 &q5, const uint4 &ch, int &n_nodes, int &n_leaves) {
+/* NC: the children a lane tests - all four of its record, or two when two lanes share a record (bx: their 6 NC box
+ * coordinates, code: their codes). */
+template <int NC>
+__device__ __forceinline__ void children_step(const DScene &sc, WaveLDS *w, int lane, unsigned long long have_mask, int rl, float item_t, const float (&bx)[6 * NC],
+                                              const uint32_t (&code)[NC], int &n_nodes, int &n_leaves) {
     const float thrf = w->thrf[rl];
     const float iux = w->rayf[0][rl], iuy = w->rayf[1][rl], iuz = w->rayf[2][rl];
     const float ncx = w->rayf[3][rl], ncy = w->rayf[4][rl], ncz = w->rayf[5][rl];
@@ -760,13 +766,10 @@ __device__ __forceinline__ void wide_children(const DScene &sc, WaveLDS *w, int 
      * into lane predicates only where something is stored: the ballot of a combined lane condition costs two vector
      * instructions more than the ballot of a plain compare. */
     const unsigned long long bh = have_mask & wave_ballot(!(item_t > thrf)); /* not fallen behind the threshold since it was pushed */
-    const float bx[24] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w,
-                          q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w};
-    const uint32_t code[4] = {ch.x, ch.y, ch.z, ch.w};
-    unsigned long long mn[4], ml[4];
-    float f[4];
+    unsigned long long mn[NC], ml[NC];
+    float f[NC];
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
+    for (int c = 0; c < NC; c++) {
         const float t1x = __builtin_fmaf(bx[6 * c], iux, ncx), t2x = __builtin_fmaf(bx[6 * c + 3], iux, ncx);
         const float t1y = __builtin_fmaf(bx[6 * c + 1], iuy, ncy), t2y = __builtin_fmaf(bx[6 * c + 4], iuy, ncy);
         const float t1z = __builtin_fmaf(bx[6 * c + 2], iuz, ncz), t2z = __builtin_fmaf(bx[6 * c + 5], iuz, ncz);
@@ -785,10 +788,10 @@ __device__ __forceinline__ void wide_children(const DScene &sc, WaveLDS *w, int 
     }
     /* Places on the stacks: all first children, then all second children, ... - the lane's place among them by mbcnt,
      * the offsets by scalar popcounts. No prefix sum over the lanes is needed. */
-    int jn[4], jl[4];
+    int jn[NC], jl[NC];
     int tn = n_nodes, tl = n_leaves;
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
+    for (int c = 0; c < NC; c++) {
         jn[c] = tn + rank_in(mn[c]);
         jl[c] = tl + rank_in(ml[c]);
         tn += __popcll(mn[c]);
@@ -798,13 +801,20 @@ __device__ __forceinline__ void wide_children(const DScene &sc, WaveLDS *w, int 
         if (lane == 0) atomicOr(sc.overflow, 1);
     } else {
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
+        for (int c = 0; c < NC; c++) {
             if (__builtin_amdgcn_inverse_ballot_w64(mn[c])) w->node[jn[c]] = make_uint2(code[c] | ((uint32_t)rl << RT_NODE_BITS), __float_as_uint(f[c]));
             if (__builtin_amdgcn_inverse_ballot_w64(ml[c])) w->leaf[jl[c]] = make_uint2(code[c], leaf_word(f[c], (uint32_t)rl));
         }
         n_nodes = tn;
         n_leaves = tl;
     }
+}
+__device__ __forceinline__ void wide_children(const DScene &sc, WaveLDS *w, int lane, unsigned long long have_mask, int rl, float item_t, const float4 &q0, const float4 &q1,
+                                              const float4 &q2, const float4 &q3, const float4 &q4, const float4 &q5, const uint4 &ch, int &n_nodes, int &n_leaves) {
+    const float bx[24] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w,
+                          q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w};
+    const uint32_t code[4] = {ch.x, ch.y, ch.z, ch.w};
+    children_step<4>(sc, w, lane, have_mask, rl, item_t, bx, code, n_nodes, n_leaves);
 }
 
 /* The pool traversal of one query: everything between "the rays' tables are in LDS" (ray_begin) and "the rays' best
@@ -1064,6 +1074,40 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
                 int k = n_nodes < RT_WAVE ? n_nodes : RT_WAVE;
                 const int room = (node_soft - n_nodes) / 3;
                 if (k > room) k = room > 1 ? room : 1;
+#if RT_NARROW_STEP
+                if (k <= RT_WAVE / 2) {
+                    /* Half a step's worth of records or fewer: two lanes share a record, each tests two of its children
+                     * (their boxes are 48 consecutive bytes, their codes 8) - half the arithmetic and half the pushes per
+                     * lane in the steps that end a query. */
+                    const int li = lane >> 1, sub = lane & 1;
+                    const unsigned long long in_k2 = wave_ballot(li < k);
+                    const uint2 it2 = w->node[__builtin_amdgcn_inverse_ballot_w64(in_k2) ? n_nodes - 1 - li : 0];
+                    n_nodes -= k;
+                    wave_sync();
+                    const int rl2 = (int)(it2.x >> RT_NODE_BITS);
+                    uint32_t rec2 = it2.x & RT_LOW_MASK;
+                    const unsigned long long outside2 = in_k2 & wave_ballot(rec2 >= n_recs);
+                    if (__builtin_expect(outside2 != 0ull, 0)) {
+                        if (lane == 0) atomicOr(sc.overflow, 2);
+                    }
+                    const unsigned long long have2 = in_k2 & ~outside2;
+                    if (!__builtin_amdgcn_inverse_ballot_w64(have2)) rec2 = 0;
+                    if (CNT && SPHP && __builtin_amdgcn_inverse_ballot_w64(have2)) cnt.sph_nodes += 2; /* two box tests per lane */
+                    const float4 *hp = reinterpret_cast<const float4 *>(tree4 + rec2) + 3 * sub;
+                    const float4 h0 = hp[0], h1 = hp[1], h2 = hp[2];
+                    const uint2 hc = reinterpret_cast<const uint2 *>(reinterpret_cast<const float4 *>(tree4 + rec2) + 6)[sub];
+                    const float hb[12] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w, h2.x, h2.y, h2.z, h2.w};
+                    const uint32_t hcode[2] = {hc.x, hc.y};
+                    children_step<2>(sc, w, lane, have2, rl2, __uint_as_float(it2.y), hb, hcode, n_nodes, n_leaves);
+                    wave_sync();
+                    if (CNT) {
+                        uint64_t t = RT_STAMP();
+                        if (SPHP && !RT_STAMP_STEPS) { cnt.dbg[0] += t - st0; cnt.dbg[1]++; cnt.dbg[2] += (uint64_t)k; }
+                        cnt.cyc_node += t - st0; st0 = t; cnt.node_steps++; cnt.node_lanes += (uint64_t)k;
+                    }
+                    continue;
+                }
+#endif
                 const unsigned long long in_k = wave_ballot(lane < k);
                 const uint2 it = w->node[__builtin_amdgcn_inverse_ballot_w64(in_k) ? n_nodes - 1 - lane : 0];
                 n_nodes -= k;
