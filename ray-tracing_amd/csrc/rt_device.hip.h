@@ -104,7 +104,9 @@ namespace rtd {
                                      instructions (elsewhere RT_SHADE_PRIO): 1, 2, 3 all +1.2 % on the battle scene; the reverse -0.7 % */
 #endif
 #ifndef RT_NARROW_STEP
-#define RT_NARROW_STEP 1          /* node steps with at most 32 records give each record two lanes */
+#define RT_NARROW_STEP 2          /* 1: node steps with at most 32 records give each record two lanes (two children per lane); 2: and those
+                                     with at most 16 four lanes (one child per lane): the steps that end a query are shorter (0 -> 1: cfg4
+                                     +1.3 %, cfg5 +5.3 %, cfg3 +2.3 %; 1 -> 2: +0.2 %, cfg5 +3.7 %) */
 #endif
 #ifndef RT_SHADE_PRIO
 #define RT_SHADE_PRIO 0
@@ -1074,6 +1076,38 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
                 int k = n_nodes < RT_WAVE ? n_nodes : RT_WAVE;
                 const int room = (node_soft - n_nodes) / 3;
                 if (k > room) k = room > 1 ? room : 1;
+#if RT_NARROW_STEP > 1
+                if (k <= RT_WAVE / 4) {
+                    /* a quarter of a step's worth or fewer: four lanes per record, one child each (24 + 4 bytes) */
+                    const int li = lane >> 2, sub = lane & 3;
+                    const unsigned long long in_k4 = wave_ballot(li < k);
+                    const uint2 it4 = w->node[__builtin_amdgcn_inverse_ballot_w64(in_k4) ? n_nodes - 1 - li : 0];
+                    n_nodes -= k;
+                    wave_sync();
+                    const int rl4 = (int)(it4.x >> RT_NODE_BITS);
+                    uint32_t rec4 = it4.x & RT_LOW_MASK;
+                    const unsigned long long outside4 = in_k4 & wave_ballot(rec4 >= n_recs);
+                    if (__builtin_expect(outside4 != 0ull, 0)) {
+                        if (lane == 0) atomicOr(sc.overflow, 2);
+                    }
+                    const unsigned long long have4 = in_k4 & ~outside4;
+                    if (!__builtin_amdgcn_inverse_ballot_w64(have4)) rec4 = 0;
+                    if (CNT && SPHP && __builtin_amdgcn_inverse_ballot_w64(have4)) cnt.sph_nodes += 1;
+                    const float2 *cp = reinterpret_cast<const float2 *>(tree4 + rec4) + 3 * sub;
+                    const float2 c0 = cp[0], c1 = cp[1], c2 = cp[2];
+                    const uint32_t cc = reinterpret_cast<const uint32_t *>(reinterpret_cast<const float4 *>(tree4 + rec4) + 6)[sub];
+                    const float cb[6] = {c0.x, c0.y, c1.x, c1.y, c2.x, c2.y};
+                    const uint32_t ccode[1] = {cc};
+                    children_step<1>(sc, w, lane, have4, rl4, __uint_as_float(it4.y), cb, ccode, n_nodes, n_leaves);
+                    wave_sync();
+                    if (CNT) {
+                        uint64_t t = RT_STAMP();
+                        if (SPHP && !RT_STAMP_STEPS) { cnt.dbg[0] += t - st0; cnt.dbg[1]++; cnt.dbg[2] += (uint64_t)k; }
+                        cnt.cyc_node += t - st0; st0 = t; cnt.node_steps++; cnt.node_lanes += (uint64_t)k;
+                    }
+                    continue;
+                }
+#endif
 #if RT_NARROW_STEP
                 if (k <= RT_WAVE / 2) {
                     /* Half a step's worth of records or fewer: two lanes share a record, each tests two of its children
