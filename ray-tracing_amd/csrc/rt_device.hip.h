@@ -543,7 +543,7 @@ __device__ __forceinline__ void hit_none(HitRec &h) {
 /* the margins of the sphere tree's boxes hold for rays that start within DScene::sph_reach of the coordinate origin */
 __device__ __forceinline__ bool sphere_walk_ok(const DScene &sc, V3 C) { return fabs(C.x) < sc.sph_reach && fabs(C.y) < sc.sph_reach && fabs(C.z) < sc.sph_reach; }
 
-__device__ __forceinline__ void ray_tables(const DScene &sc, WaveLDS *w, int slot, const RayQ &q, bool prune, const HitRec &h);
+__device__ __forceinline__ void ray_tables(const DScene &sc, WaveLDS *w, int slot, const RayQ &q, bool prune, const HitRec &h, bool ray_in_place = false);
 /* Spheres for one ray and the ray's entry in the pool's tables. */
 template <bool CNT, bool SPH, typename SP>
 __device__ __forceinline__ void ray_begin(const DScene &sc, WaveLDS *w, SP sph, int slot, const RayQ &q, bool prune, bool spheres_done,
@@ -559,7 +559,7 @@ __device__ __forceinline__ void ray_begin(const DScene &sc, WaveLDS *w, SP sph, 
         for (int s = 0; s < n_sph; s++) sphere_test_counted(sph, s, C, u, h);
     }
     if (CNT) { cnt.sph_tests += (uint64_t)h.sph_tests; cnt.sph_nodes += (uint64_t)h.sph_nodes; }
-    ray_tables(sc, w, slot, q, prune, h);
+    ray_tables(sc, w, slot, q, prune, h, spheres_done); /* spheres_pool has left the ray and its constants in the tables */
 }
 
 /* Sphere::intersect and Scene::intersect's choice (sphere_test above) for a lane's two rays at once and without branches:
@@ -599,7 +599,8 @@ __device__ __forceinline__ void sphere_test2(SP sph, int s, const RayQ &qa, cons
 }
 
 /* The pool's table entries of one ray once its closest sphere is known (h). */
-__device__ __forceinline__ void ray_tables(const DScene &sc, WaveLDS *w, int slot, const RayQ &q, bool prune, const HitRec &h) {
+/* ray_in_place: the ray, its box-test constants and its tolerance are in the tables already (same ray, same mode) */
+__device__ __forceinline__ void ray_tables(const DScene &sc, WaveLDS *w, int slot, const RayQ &q, bool prune, const HitRec &h, bool ray_in_place) {
     if (!q.active || sc.n_meshes == 0) return;
     const V3 C = q.C, u = q.u;
     /* Mesh hits are accepted only below t0 = min(1E9, sphere hit, tmax): TriangleMesh::intersect starts at
@@ -611,13 +612,15 @@ __device__ __forceinline__ void ray_tables(const DScene &sc, WaveLDS *w, int slo
         if (q.tmax < t0) t0 = q.tmax;
         if (!(t0 > 0)) t0 = 0; /* also turns -0.0 into +0.0: the bit pattern must order like the value */
     }
-    const RayK k = ray_constants(sc, C, u);
-    w->ray[0][slot] = C.x; w->ray[1][slot] = C.y; w->ray[2][slot] = C.z;
-    w->ray[3][slot] = u.x; w->ray[4][slot] = u.y; w->ray[5][slot] = u.z;
-    w->rayf[0][slot] = (float)k.iu.x; w->rayf[1][slot] = (float)k.iu.y; w->rayf[2][slot] = (float)k.iu.z;
-    w->rayf[3][slot] = (float)k.nc.x; w->rayf[4][slot] = (float)k.nc.y; w->rayf[5][slot] = (float)k.nc.z;
-    const float tf = (float)(k.tol * RT_TOLF_SCALE);
-    w->tolf[slot] = (q.anyhit && prune) ? -tf : tf; /* the sign bit of a NaN is kept too */
+    if (!ray_in_place) {
+        const RayK k = ray_constants(sc, C, u);
+        w->ray[0][slot] = C.x; w->ray[1][slot] = C.y; w->ray[2][slot] = C.z;
+        w->ray[3][slot] = u.x; w->ray[4][slot] = u.y; w->ray[5][slot] = u.z;
+        w->rayf[0][slot] = (float)k.iu.x; w->rayf[1][slot] = (float)k.iu.y; w->rayf[2][slot] = (float)k.iu.z;
+        w->rayf[3][slot] = (float)k.nc.x; w->rayf[4][slot] = (float)k.nc.y; w->rayf[5][slot] = (float)k.nc.z;
+        const float tf = (float)(k.tol * RT_TOLF_SCALE);
+        w->tolf[slot] = (q.anyhit && prune) ? -tf : tf; /* the sign bit of a NaN is kept too */
+    }
     w->best_t[slot] = (unsigned long long)__double_as_longlong(t0);
     w->best_pos[slot] = INT32_MAX;
     /* While nothing closer than 1E9 is known, nothing may be skipped by distance: a triangle hit at or beyond
