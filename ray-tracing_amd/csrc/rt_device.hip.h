@@ -1833,7 +1833,7 @@ __device__ __forceinline__ void render_persistent(const DScene &sc, const DScene
         const bool tracing = !q.finished;
         if (__ballot(tracing) == 0ull) {
             if (__ballot(!exhausted || have) == 0ull) break;
-            continue; /* nothing to trace this round: only bookkeeping (pixels ended or were just assigned) */
+            continue; /* nothing to trace in this iteration: only bookkeeping (pixels ended or were just assigned) */
         }
         if (CNT) cnt.cyc_fresh += RT_STAMP() - sp0;
         HitRec h, hs;
