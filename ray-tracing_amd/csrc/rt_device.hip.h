@@ -1438,10 +1438,14 @@ __device__ __forceinline__ void hit_surface(const DScene &sc, SP sph, V3 C, V3 u
             V = V * (double)H;
             int uvx = (int)(U + 0.5);
             int uvy = (int)(V + 0.5);
-            uvx = uvx % W;
-            uvy = uvy % H;
-            if (uvx < 0) uvx += W;
-            if (uvy < 0) uvy += H;
+            /* uvx % W, uvy % H with negative results wrapped (:706-712). Texture coordinates inside [0, 1) - the usual case -
+             * are in range already; the division is only run by a wave in which some lane needs it. */
+            if (__builtin_expect(wave_ballot((unsigned)uvx >= (unsigned)W || (unsigned)uvy >= (unsigned)H) != 0ull, 0)) {
+                uvx = uvx % W;
+                uvy = uvy % H;
+                if (uvx < 0) uvx += W;
+                if (uvy < 0) uvy += H;
+            }
             uvy = H - uvy - 1;
             const uint8_t *px = in_global(sc.texels) + tx.offset + ((int64_t)uvy * W + uvx) * 3;
             const double *lut = in_global(sc.lut);
