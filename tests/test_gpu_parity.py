@@ -256,6 +256,34 @@ def test_stochastic_per_sample(gpu, rta, scenes, ob, name, kw):
     _check_samples(gpu, orc, cam, p, ijk)
 
 
+def test_texture_coordinates_outside_the_texture(gpu, rta, scenes, ob, probe_mode):
+    """texture coordinates below 0 and above 1: uvx % W, uvy % H with negative results wrapped (raytracer.cpp:706-712); the
+    kernel divides only where a coordinate is out of range, so both ways through that code are compared with the oracle"""
+    W = 96
+    s = rta.Scene(I=6e9, L=(-10, 50, 40))
+    s.add(rta.Sphere(s.L, 5, (1, 1, 1)))
+    scenes._room(s)
+    n = scenes.grid_for_triangles(8000)
+    v, nn, uv, ix = scenes.blob_mesh(n, size=(9.0, 6.0, 8.0), offset=(0.0, 0.0, 8.5), seed=5, n_groups=1)
+    for scale, shift, dx in ((3.0, -1.2, -12), (1.0, 0.0, 12)):  # one mesh far outside [0, 1], one inside
+        m = rta.TriangleMesh((0, 1, 1))
+        m.set_raw(v, nn, np.asarray(uv) * scale + shift, ix)
+        m.addTexture(scenes.procedural_texture(64, 11))
+        m.rotate(1, 2).rotate(0, 2).translate(1, -10).translate(0, dx)
+        m.buildBVH()
+        s.add(m)
+    cam = rta.make_camera((0, 30, 55), 60.0, -25.0, 0.0, W)
+    orc = ob.OracleScene(scenes.export_objects(s), s.I, s.L, math="portable")
+    gpu.upload(s)
+    rays, _ = ob.primary_rays(cam, W, W)
+    g, o = gpu.intersect_rays(rays), orc.intersect_rays(rays)
+    assert (o["tri"] >= 0).sum() > 300
+    _check_hits(g, o)
+    p = rta.make_params(W, W, 2)
+    ijk = np.array([(i, j, k) for i in range(0, W, 2) for j in range(0, W, 2) for k in range(2)], np.int32)
+    _check_samples(gpu, orc, cam, p, ijk)
+
+
 @pytest.mark.parametrize("max_rebond", [0, 1, 2, 5])
 @pytest.mark.parametrize("name,kw", [("sphere_room", dict(W=48)), ("mesh_room", dict(W=48, n_tris=5000, tex_size=64))])
 def test_depth_limit_and_rays_left_out(gpu, rta, scenes, ob, name, kw, max_rebond):
