@@ -1754,18 +1754,8 @@ __device__ __forceinline__ V3 trace_pixel(const DScene &sc, const DScene &cold, 
     return q.acc;
 }
 
-/* slot -> pixel of the render rectangle: slots run over 8x8 pixel tiles (64 consecutive slots = one tile) so the
- * camera rays a wave starts together stay together */
-__device__ __forceinline__ bool slot_pixel(const RenderArgs &ra, int64_t slot, int &i, int &j) {
-    const int rw = ra.j1 - ra.j0;
-    const int tiles_x = (rw + 7) >> 3;
-    const int tile = (int)(slot >> 6), ln = (int)(slot & 63);
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    j = ra.j0 + tx * 8 + (ln & 7);
-    i = ra.i0 + ty * 8 + (ln >> 3);
-    return (j < ra.j1) && (i < ra.i1);
-}
-
+/* Slots run over 8x8 pixel tiles of the render rectangle (64 consecutive slots = one tile), so the camera rays a wave
+ * starts together stay together. */
 /* The render loop of a persistent wave. Lanes take pixels ("slots") from a global counter, one 64-slot tile
  * per request; a lane keeps its pixel for all nk samples (added in order, raytracer.cpp:1464-1486), writes the
  * sum and takes the next free slot. Because lanes re-fill independently, the wave's pool stays full until the
@@ -1788,6 +1778,7 @@ __device__ __forceinline__ void render_persistent(const DScene &sc, const DScene
     bool have = false, exhausted = false;
     int i = 0, j = 0;
     int cur = 0, end = 0; /* wave-uniform: the part of the last tile request not handed out yet */
+    int tile_c = 0, tile_i = 0, tile_j = 0; /* wave-uniform: that request's chunk and the pixel of its tile's corner */
     const bool prune = PLAIN ? true : !(ra.p.flags & RT_F_NO_PRUNE); /* also: rays without effect are not traced (path_advance) */
     uint64_t sp0 = 0;
     while (true) {
@@ -1807,7 +1798,7 @@ __device__ __forceinline__ void render_persistent(const DScene &sc, const DScene
             }
             have = false;
         }
-        const unsigned long long need = __ballot(!have && !exhausted);
+        const unsigned long long need = wave_ballot(!have && !exhausted);
         if (need) {
             if (cur == end) { /* one atomic per tile */
                 int base = 0;
@@ -1815,16 +1806,26 @@ __device__ __forceinline__ void render_persistent(const DScene &sc, const DScene
                 cur = uni(base);
                 end = cur + RT_WAVE < n_total ? cur + RT_WAVE : n_total;
                 if (cur >= n_total) { cur = end = n_total; }
+                /* The 64 slots of a request are one tile of one chunk (requests and the slots per chunk are multiples of
+                 * 64): the chunk and the tile's corner are found once per request, with wave-uniform divisions, and a lane
+                 * only adds its place inside the tile. */
+                tile_c = uni(cur / n_slots);
+                const int tile = (cur - tile_c * n_slots) >> 6, tiles_x = (ra.j1 - ra.j0 + 7) >> 3;
+                const int ty = uni(tile / tiles_x);
+                tile_i = ra.i0 + ty * 8;
+                tile_j = ra.j0 + (tile - ty * tiles_x) * 8;
             }
             if (!have && !exhausted) {
                 const int mine = cur + rank_in(need);
                 if (cur >= n_total) {
                     exhausted = true;
                 } else if (mine < end) {
-                    const int c = mine / n_slots;
-                    const bool live = slot_pixel(ra, mine - c * n_slots, i, j);
-                    const int ks = k0 + c * chunk;
-                    unit_c = c;
+                    const int ln = mine & 63;
+                    j = tile_j + (ln & 7);
+                    i = tile_i + (ln >> 3);
+                    const bool live = (j < ra.j1) && (i < ra.i1);
+                    const int ks = k0 + tile_c * chunk;
+                    unit_c = tile_c;
                     kend_l = ks + chunk < kend ? ks + chunk : kend;
                     path_begin(q, ks, live);
                     have = live; /* a slot outside the rectangle is skipped */
@@ -1835,8 +1836,8 @@ __device__ __forceinline__ void render_persistent(const DScene &sc, const DScene
         }
         path_fresh<CNT, PLAIN>(ra, q, i, j, kend_l, cnt);
         const bool tracing = !q.finished;
-        if (__ballot(tracing) == 0ull) {
-            if (__ballot(!exhausted || have) == 0ull) break;
+        if (wave_ballot(tracing) == 0ull) {
+            if (wave_ballot(!exhausted || have) == 0ull) break;
             continue; /* nothing to trace in this iteration: only bookkeeping (pixels ended or were just assigned) */
         }
         if (CNT) cnt.cyc_fresh += RT_STAMP() - sp0;
