@@ -2,7 +2,9 @@
 """Benchmark of the path-tracing hot path: Mpaths/s and time-to-image.
 
   python bench.py --gpus N --steps K --warmup W [--config cfg1|cfg2|cfg3|cfg4|cfg5]
-  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1 without a launcher (no WORLD_SIZE in the environment): this script starts `python -m torch.distributed.run
+  --nproc-per-node N` on itself, one rank per GPU, before anything touches the GPU, and passes the ranks' exit code on;
+  under an external `torch.distributed.run` it runs as the rank it is given.
 
 Default workload = cfg4, the configuration the metric is quoted on: the final battle scene of main()
 (raytracer.cpp:1222-1435) at 1024 x 1024. The other configurations of BASELINE.json can be selected for
@@ -73,6 +75,22 @@ def lib_sha16(path):
     return h.hexdigest()[:16]
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def spawn_ranks(n, argv, run=None, port=None):
+    """Start one process per GPU on this script (the parallelism a caller of the reference gets from its one OpenMP line,
+    raytracer.cpp:1456) and return their exit code. Called before torch is imported: this process never touches the GPU."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port or free_port()), os.path.abspath(__file__)] + list(argv)
+    return (run or subprocess.run)(cmd).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,14 +106,17 @@ def main():
     ap.add_argument("--out-png", default="")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        ap.error("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world), file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+            print("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
 
     import ctypes
     import torch
@@ -104,8 +125,14 @@ def main():
     # RT_BENCH_BACKEND=gloo is for rehearsing the multi-rank path on a box with fewer GPUs than ranks (ranks then share
     # devices, which RCCL refuses); the measured configuration is one GPU per rank over RCCL.
     backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
     if backend != "nccl":
-        local_rank = local_rank % max(1, torch.cuda.device_count())
+        local_rank = local_rank % max(1, n_dev)
+    elif world > n_dev:
+        if rank == 0:
+            print("bench.py: --gpus %d but this node has %d GPU(s) (one rank per GPU over RCCL; RT_BENCH_BACKEND=gloo lets ranks "
+                  "share a GPU for a rehearsal)" % (world, n_dev), file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     if world > 1:
         if backend == "nccl":
@@ -324,8 +351,12 @@ def main():
                                                    "sample": "%d spp, %.1f s: /root/reference/raytracer.cpp's own classes, OpenMP rows, shared engine(10) + rand() as committed" % (ref_spp, dt_ref)}
         out = {"metric": "Mpaths/s (whole node) final scene 1024x1024" if args.config == "cfg4" else "Mpaths/s (whole node) %s %dx%d" % (args.config, W, H),
                "value": round(value, 3), "unit": "Mpaths/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "n_gpus": world, "world_size": dist.get_world_size() if world > 1 else 1, "backend": ("RCCL" if backend == "nccl" else backend) if world > 1 else None,
+               "devices_on_node": n_dev, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak",
+               "scaling_note": "per-rank work per step is fixed (value); time_to_image is the fixed-size image split over the ranks. No 1/2/4/8-GPU curve of "
+                               "this build has been measured on hardware yet: only one-GPU boxes were available to it",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": "%s, %d triangles, %d BVH records, %d spheres, %dx%d, %d spp per rank per step" % (what, info["n_tris"], info["n_nodes"], info["n_spheres"], W, H, spp_step),
                           "name": args.config, "spp_per_step": spp_step,
                           "parallelism": "spp-sharded x%d + %s reduce(sum) of the f64 accumulator" % (world, "RCCL" if backend == "nccl" else backend),

@@ -78,3 +78,56 @@ def test_split_samples_covers_the_image():
                 assert 0 <= lo <= hi <= total and hi - lo <= -(-total // world)
                 got += list(range(lo, hi))
             assert got == list(range(total))
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rt_bench_script", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_bench_starts_its_own_ranks(monkeypatch):
+    """`bench.py --gpus N` without a launcher starts torch.distributed.run on itself, before torch is imported, and passes
+    the ranks' exit code on; under a launcher (WORLD_SIZE set) it does not spawn again."""
+    bench = _load_bench()
+    seen = {}
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd):
+        seen["cmd"] = cmd
+        return Done()
+
+    rc = bench.spawn_ranks(4, ["--gpus", "4", "--steps", "2", "--warmup", "1"], run=fake_run, port=29123)
+    assert rc == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29123"
+    k = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[k + 1:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"]
+
+    # main(): spawns when no launcher set WORLD_SIZE, exits with the children's code
+    calls = []
+    monkeypatch.setattr(bench, "spawn_ranks", lambda n, argv: calls.append((n, list(argv))) or 3)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "1"])
+    try:
+        bench.main()
+        assert False, "main() should have exited"
+    except SystemExit as e:
+        assert e.code == 3
+    assert calls == [(2, ["--gpus", "2", "--steps", "1"])]
+    # a launcher that started a different number of ranks is an error, not a silent mismatch
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setenv("RANK", "1")
+    calls.clear()
+    try:
+        bench.main()
+        assert False
+    except SystemExit as e:
+        assert e.code == 2
+    assert calls == []
