@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP64_VECTOR_TFLOPS = 78.6   # MI355X vector FP64 with every instruction an FMA = half the 157.3 TFLOP/s FP32 vector peak
+PEAK_FP32_VECTOR_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
 # name -> (scene builder name, builder kwargs, frame size, samples of a step, samples of the finished image, CPU baseline samples, description)
@@ -48,17 +49,29 @@ CONFIGS = {
 }
 
 
-def algorithmic_flops(c, n_spheres, own=False):
-    """Flops of a counted run (add/sub/mul/div/sqrt/compare = 1; cos/sin/log are counted separately as
-    transcendentals): per ray n_spheres*20 + 25 for the sphere that is hit, 24 per box test, 54 per triangle
-    test; per path 60 for the camera sample; 150 per diffuse vertex, 40 per specular vertex."""
-    sphere_work = c["rays"] * n_spheres * 20  # the algorithm as stated: every ray tests every sphere (raytracer.cpp:934-938)
-    if "sphere_tests" in c and own:           # the kernel's own work: the exact tests it did + the boxes of its sphere tree
-        sphere_work = c["sphere_tests"] * 20 + c["sphere_nodes"] * 24
+def algorithmic_flops(c, n_spheres):
+    """Flops of the algorithm as the reference states it, from a counted run with the reference's traversal (add/sub/mul/div/
+    sqrt/compare = 1; cos/sin/log are counted separately as transcendentals): per ray n_spheres*20 + 25 for the sphere that is
+    hit, 24 per box test, 54 per triangle test; per path 60 for the camera sample; 150 per diffuse vertex, 40 per specular
+    vertex."""
+    sphere_work = c["rays"] * n_spheres * 20  # every ray tests every sphere (raytracer.cpp:934-938)
     flops = (sphere_work + c["rays"] * 25 + c["box_tests"] * 24 + c["tris"] * 54 + c["paths"] * 60 +
              c["diffuse"] * 150 + c["specular"] * 40)
     transc = c["paths"] * 8 + c["diffuse"] * 4
     return flops, transc
+
+
+def production_flops(c):
+    """(FP64 flops, FP32 flops) of a counted run of the production traversal, by the same rule. Single precision: every box
+    test of the filter tree, of the tree over a long sphere list, of the mesh roots and of the second pass's records (24
+    each). Double precision: exact sphere tests (20) + 25 per ray for the sphere that is hit, triangle tests including the
+    second evaluation of a confirmed winner (54), box tests in the reference's double-precision form - undecided
+    single-precision tests and the confirmation of a filter-tree winner - (24), camera sample (60), diffuse (150) and
+    specular (40) vertices."""
+    f32 = (c["box_tests"] + c["sphere_nodes"]) * 24
+    f64 = (c["sphere_tests"] * 20 + c["rays"] * 25 + c["tris"] * 54 + c["box_exact"] * 24 + c["paths"] * 60 +
+           c["diffuse"] * 150 + c["specular"] * 40)
+    return f64, f32
 
 
 def algorithmic_bytes(c, node_bytes):
@@ -262,50 +275,73 @@ def main():
                        "render = %d samples per pixel split over %d rank(s), reduce to rank 0, tone map, image in host memory" % (spp_image, world)}
 
     if rank == 0:
-        # counted runs (separate, untimed): the work the kernel really does ("own": the default pruned traversal with
-        # any-hit shadow rays, on the reference's trees - the filter tree visits fewer records still) and the work of
-        # the algorithm as the reference states it (every node whose box the ray's line crosses, RT_F_NO_PRUNE).
+        # Counted runs (separate, untimed). "production": the counted variant of the render kernel walking exactly what the
+        # timed kernel walks (filter tree with single-precision box tests, any-hit shadow rays, rays without effect left out,
+        # second pass on the reference's trees for unconfirmed rays) - the numerator of roofline.achieved / frac.
+        # "reference": the algorithm as the reference states it (every node whose box the ray's line crosses,
+        # RT_F_NO_PRUNE, on the reference's trees; equal to the CPU checker's counters).
         cnt_spp = 2
         scratch = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
         counted = {}
-        for label, extra in (("reference", rta.RT_F_NO_PRUNE), ("own", 0)):
+        for label, extra, own in (("reference", rta.RT_F_NO_PRUNE, 0), ("production", 0, 1)):
+            rta.lib.rt_debug_count_own(r._h, own)
             r.reset_counters()
             r.render(cam, rta.make_params(W, H, cnt_spp, spp_offset=0, flags=flags | rta.RT_F_COUNTERS | extra), scratch.data_ptr())
             r.sync()
             counted[label] = r.counters()
-            dbg = (ctypes.c_uint64 * 22)()
+            dbg = (ctypes.c_uint64 * 24)()
             rta.lib.rt_debug_stats(r._h, dbg)
-            counted[label]["sphere_tests"], counted[label]["sphere_nodes"] = int(dbg[20]), int(dbg[21])
-        c, g = counted["reference"], counted["own"]
+            counted[label].update(sphere_tests=int(dbg[20]), sphere_nodes=int(dbg[21]), box_exact=int(dbg[22]), redo_rays=int(dbg[18]),
+                                  node_steps=int(dbg[6]), node_lanes=int(dbg[7]), leaf_steps=int(dbg[8]), leaf_lanes=int(dbg[9]), queries=int(dbg[10]))
+        rta.lib.rt_debug_count_own(r._h, 0)
+        c, g = counted["reference"], counted["production"]
         paths_per_launch = float(W) * H * spp_step * args.steps / max(1, kernel_launches)
         avg_launch_s = kernel_ms / 1e3 / max(1, kernel_launches)
-        own_flops = algorithmic_flops(g, info["n_spheres"], own=True)[0] / g["paths"]
-        own_bytes = algorithmic_bytes(g, node_bytes=64) / g["paths"]       # the kernel's records: 64 B with float boxes
+        f64, f32 = production_flops(g)
+        f64, f32 = f64 / g["paths"], f32 / g["paths"]
+        # bytes the production traversal asks for: 128 B per filter-tree record, 80 B per triangle tested, per shaded vertex the
+        # winner's triangle, leaf index, leaf box and attribute record (80 + 4 + 24 + 128), 24 B accumulate per path
+        own_bytes = (g["nodes"] * 128 + g["tris"] * 80 + (g["diffuse"] + g["specular"]) * 236 + g["paths"] * 24) / g["paths"]
         ref_flops, ref_transc = algorithmic_flops(c, info["n_spheres"])
         ref_flops /= c["paths"]
         ref_bytes = algorithmic_bytes(c, node_bytes=128) / c["paths"]      # two FP64 boxes + links, as the reference holds them
-        own_tflops = own_flops * paths_per_launch / avg_launch_s / 1e12
-        ref_tflops = ref_flops * paths_per_launch / avg_launch_s / 1e12
+        scale = paths_per_launch / avg_launch_s / 1e12
+        own_tflops = (f64 + f32) * scale
+        t_floor = f64 * scale / PEAK_FP64_VECTOR_TFLOPS + f32 * scale / PEAK_FP32_VECTOR_TFLOPS  # = time at peak / time taken
+        blended_peak = own_tflops / t_floor if t_floor > 0 else PEAK_FP64_VECTOR_TFLOPS
+        ref_tflops = ref_flops * scale
         own_gbs = own_bytes * paths_per_launch / avg_launch_s / 1e9
         kname = "rt_render_spheres_kernel<false>" if info["n_spheres"] > 64 else ("rt_render_kernel<false, true>" if flags == 0 else "rt_render_kernel<false, false>")
         roofline = {
-            "bound": "valu_fp64", "achieved": round(own_tflops, 4), "peak": PEAK_FP64_VECTOR_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(own_tflops / PEAK_FP64_VECTOR_TFLOPS, 5), "own_work_frac": round(own_tflops / PEAK_FP64_VECTOR_TFLOPS, 5),
-            "frac_of_fma_less_peak": round(own_tflops / (PEAK_FP64_VECTOR_TFLOPS / 2), 5),
+            "bound": "valu", "achieved": round(own_tflops, 4), "peak": round(blended_peak, 2), "unit": "TFLOP/s",
+            "frac": round(t_floor, 5),
+            "flops_fp64": round(f64 * paths_per_launch, 1), "flops_fp32": round(f32 * paths_per_launch, 1),
+            "peak_fp64": PEAK_FP64_VECTOR_TFLOPS, "peak_fp32": PEAK_FP32_VECTOR_TFLOPS,
+            "frac_fp64_part": round(f64 * scale / PEAK_FP64_VECTOR_TFLOPS, 5), "frac_fp32_part": round(f32 * scale / PEAK_FP32_VECTOR_TFLOPS, 5),
             "traffic": None, "kernel": kname, "avg_launch_ms": round(avg_launch_s * 1e3, 3), "launches": kernel_launches,
             "paths_per_launch": paths_per_launch,
-            "definition": "achieved = flops the kernel's own traversal executes (counted variant of the same kernel) per launch / mean launch "
-                          "duration (HIP events on the render stream over the timed region); no FMA contraction (-ffp-contract=off), so the "
-                          "ceiling for this instruction mix is peak / 2",
-            "own_work": {"flops_per_path": round(own_flops, 1), "bytes_per_path": round(own_bytes, 1), "nodes_per_path": round(g["nodes"] / g["paths"], 2),
-                         "tris_per_path": round(g["tris"] / g["paths"], 2), "sphere_tests_per_ray": round(g["sphere_tests"] / max(1, g["rays"]), 2),
-                         "sphere_tree_nodes_per_ray": round(g["sphere_nodes"] / max(1, g["rays"]), 2), "requested_GBs": round(own_gbs, 2),
-                         "note": "bytes the traversal asks for (records, triangles, attributes), served mostly by L1/L2: compare `traffic` (HBM side) where a counter pass exists"},
+            "definition": "achieved = (flops_fp64 + flops_fp32) per launch / mean launch duration (HIP events on the render stream over the timed "
+                          "region); flops = what the production traversal executes, counted by the counted variant of the same kernel walking "
+                          "the same trees the timed kernel walks (filter tree in single precision, reference trees for unconfirmed rays); "
+                          "frac = (flops_fp64 / peak_fp64 + flops_fp32 / peak_fp32) / launch duration; peak = achieved / frac, the peak "
+                          "blended by this mix. No FMA contraction in the FP64 code (-ffp-contract=off): hardly any counted flop is half of an FMA, "
+                          "so an instruction-issue ceiling for this mix is about half of these peaks",
+            "production_work": {"flops_fp64_per_path": round(f64, 1), "flops_fp32_per_path": round(f32, 1), "bytes_per_path": round(own_bytes, 1),
+                                "records_per_path": round(g["nodes"] / g["paths"], 2), "box_tests_fp32_per_path": round((g["box_tests"] + g["sphere_nodes"]) / g["paths"], 2),
+                                "box_tests_fp64_per_path": round(g["box_exact"] / g["paths"], 3),
+                                "tris_per_path": round(g["tris"] / g["paths"], 2), "sphere_tests_per_ray": round(g["sphere_tests"] / max(1, g["rays"]), 2),
+                                "second_pass_rays_per_path": round(g["redo_rays"] / g["paths"], 5),
+                                "node_steps_per_query": round(g["node_steps"] / max(1, g["queries"]), 2), "node_step_fill": round(g["node_lanes"] / max(1, g["node_steps"]) / 64, 3),
+                                "triangle_steps_per_query": round(g["leaf_steps"] / max(1, g["queries"]), 2),
+                                "queries_per_path": round(g["queries"] * 64 / g["paths"], 3),
+                                "requested_GBs": round(own_gbs, 2),
+                                "note": "bytes the traversal asks for (records, triangles, attributes), served mostly by L1/L2: compare `traffic` (HBM side) where a counter pass exists; "
+                                        "queries_per_path = wave queries x 64 lanes / paths"},
             "reference_semantics": {"flops_per_path": round(ref_flops, 1), "transcendentals_per_path": round(ref_transc / c["paths"], 2),
                                     "bytes_per_path": round(ref_bytes, 1), "nodes_per_path": round(c["nodes"] / c["paths"], 2),
                                     "tris_per_path": round(c["tris"] / c["paths"], 2), "TFLOPs_equivalent": round(ref_tflops, 4),
                                     "frac_equivalent": round(ref_tflops / PEAK_FP64_VECTOR_TFLOPS, 5),
-                                    "note": "the unpruned reference algorithm's flops divided by this kernel's time: a speed-up-inclusive figure, not a utilisation"},
+                                    "note": "the unpruned reference algorithm's flops (all FP64 there) divided by this kernel's time: a speed-up-inclusive figure, not a utilisation"},
             "rays_per_path": round(c["rays"] / c["paths"], 3), "rays_traced_per_path": round(g["rays"] / g["paths"], 3),
             "rays_note": "rays_per_path = rays the reference traces; rays_traced_per_path = rays this kernel traces: the shadow ray of a vertex whose "
                          "direct term is exactly zero and the ray beyond the depth limit (intersected, then dropped, raytracer.cpp:960-963) are left out, "
@@ -314,11 +350,15 @@ def main():
         # committed counter pass of this same command ONLY if that pass was made with this very library build (hash stored
         # in the summary); FETCH_SIZE is in KB of 64 B requests, doubled for gfx950's 128-byte requests. Null otherwise.
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r2_%s_mem2.json" % args.config)))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r3_%s_mem2.json" % args.config)))
             if pm.get("lib_sha16") == lib_sha16(rta.LIB_PATH) and pm.get("spp_step") == spp_step and pm.get("size") == W:
                 kk = [k for k in pm["kernels"] if kname in k][0]
-                roofline["traffic"] = round(pm["kernels"][kk]["FETCH_SIZE"] * 1024.0 * 2.0 / pm["kernels"][kk]["dispatches"], 1)
-                roofline["traffic_note"] = "HBM-side fetch bytes per launch from profiles/r2_%s_mem2.json (same library build), x2 gfx950 correction" % args.config
+                raw = pm["kernels"][kk]["FETCH_SIZE"] * 1024.0 / pm["kernels"][kk]["dispatches"]
+                roofline["traffic"] = round(raw * 2.0, 1)
+                roofline["traffic_uncorrected"] = round(raw, 1)
+                roofline["traffic_note"] = ("HBM-side fetch bytes per launch from profiles/r3_%s_mem2.json (same library build): `traffic` with the x2 correction "
+                                            "for gfx950's 128-byte requests, which is established for wide streaming reads; this kernel gathers 64- to 128-byte "
+                                            "records, so the truth lies between `traffic_uncorrected` and `traffic`" % args.config)
         except (OSError, KeyError, IndexError, ValueError, ZeroDivisionError):
             pass
         sz = (ctypes.c_uint64 * 4)()

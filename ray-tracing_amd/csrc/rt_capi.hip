@@ -177,6 +177,7 @@ struct rt_ctx {
     double *unit_sums = nullptr; /* sums of the work units of one launch: [unit of the pixel][H][W][3] */
     size_t unit_sums_bytes = 0;
     rt_counters *d_counters = nullptr;
+    bool count_own = false; /* RT_F_COUNTERS renders walk and count the production traversal instead of the reference's */
     int *d_overflow = nullptr;
     int *d_next_slot = nullptr;
     double *d_tone = nullptr;    /* 256 tone-map thresholds (tone_thresholds) */
@@ -875,6 +876,13 @@ static int unit_for(int n_slots) {
 
 /* rt_render and rt_render_static: the same launches. use_static: the tile counter and the unit sums live in this
  * device's copy of the static scratch array and nothing is allocated. */
+/* the scene as a counted launch gets it: with the choice of what is walked and counted (rt_debug_count_own) */
+static DScene counted_scene(const rt_ctx *c) {
+    DScene d = c->sc;
+    d.count_own = c->count_own ? 1 : 0;
+    return d;
+}
+
 static int render_impl(rt_ctx *c, const rt_camera *cam, const rt_params *p, double *accum, bool use_static) {
     if (!c) return RT_E_INVALID;
     RenderArgs ra;
@@ -948,13 +956,13 @@ static int render_impl(rt_ctx *c, const rt_camera *cam, const rt_params *p, doub
         const unsigned pgrid = (unsigned)(tiles_all < resident ? tiles_all : resident);
         HIPCHK(c, hipMemsetAsync(next_slot, 0, sizeof(int), c->stream));
         if (c->sc.sph_rec4 != nullptr && (p->flags & RT_F_COUNTERS))
-            hipLaunchKernelGGL(rt_render_spheres_kernel<true>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, unit_sums, c->d_counters, next_slot, n_slots);
+            hipLaunchKernelGGL(rt_render_spheres_kernel<true>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, counted_scene(c), ra, p->spp_offset + k, nk, chunk, accum, unit_sums, c->d_counters, next_slot, n_slots);
         else if (c->sc.sph_rec4 != nullptr)
             hipLaunchKernelGGL(rt_render_spheres_kernel<false>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, unit_sums, c->d_counters, next_slot, n_slots);
         else if (p->flags == 0)
             hipLaunchKernelGGL((rt_render_kernel<false, true>), dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, unit_sums, c->d_counters, next_slot, n_slots);
         else if (p->flags & RT_F_COUNTERS)
-            hipLaunchKernelGGL(rt_render_kernel<true>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, unit_sums, c->d_counters, next_slot, n_slots);
+            hipLaunchKernelGGL(rt_render_kernel<true>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, counted_scene(c), ra, p->spp_offset + k, nk, chunk, accum, unit_sums, c->d_counters, next_slot, n_slots);
         else
             hipLaunchKernelGGL(rt_render_kernel<false>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, unit_sums, c->d_counters, next_slot, n_slots);
         HIPCHK(c, hipGetLastError());
@@ -1169,12 +1177,25 @@ int rt_get_counters(rt_ctx *c, rt_counters *out) {
     return RT_OK;
 }
 
-/* not part of the public header: 22 diagnostic words of the counted kernel variant (cycle stamps per
- * phase, pool occupancy, 8 free slots for experiments, exact sphere tests, sphere-tree nodes visited), for tools/ and bench.py's report only */
-int rt_debug_stats(rt_ctx *c, uint64_t *out22) {
+/* not part of the public header: what the renders with RT_F_COUNTERS walk and count from now on. 0 (default): the
+ * reference's traversal on the reference's trees - rt_counters then equals the CPU checker's counters. 1: what a production
+ * render walks - the filter tree with its single-precision box tests, then the reference's trees (with their extension
+ * records) for the rays whose winner was not confirmed; rt_counters.box_tests / nodes / tris then count that work, and
+ * word 22 of rt_debug_stats the double-precision box tests (undecided single-precision tests, winner confirmations). */
+int rt_debug_count_own(rt_ctx *c, int on) {
+    if (!c) return RT_E_INVALID;
+    c->count_own = on != 0;
+    return RT_OK;
+}
+
+/* not part of the public header: 24 diagnostic words of the counted kernel variant (cycle stamps per phase, pool occupancy,
+ * 8 free slots for experiments - [6] of them: rays that went round again on the reference's trees -, exact sphere tests,
+ * sphere-tree box tests, double-precision box tests, one spare), for tools/ and bench.py's report only */
+int rt_debug_stats(rt_ctx *c, uint64_t *out24) {
+    uint64_t *out22 = out24;
     if (!c || !out22) return RT_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(out22, reinterpret_cast<uint64_t *>(c->d_counters) + 8, 22 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out22, reinterpret_cast<uint64_t *>(c->d_counters) + 8, 24 * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }

@@ -99,6 +99,8 @@ namespace rtd {
                                      leaf step needs no prefix sum to spread items over lanes (cfg5: +5.6 % against 4) */
 #endif
 #ifndef RT_EXT_LEAF
+#define RT_EXT_LEAF 4             /* reference leaves with more triangles than this get extension records down to this size */
+#endif
 #ifndef RT_TRAV_PRIO
 #define RT_TRAV_PRIO 1            /* issue priority of a wave while it is in the pool traversal, whose steps are chains of dependent
                                      instructions (elsewhere RT_SHADE_PRIO): 1, 2, 3 all +1.2 % on the battle scene; the reverse -0.7 % */
@@ -110,8 +112,6 @@ namespace rtd {
 #endif
 #ifndef RT_SHADE_PRIO
 #define RT_SHADE_PRIO 0
-#endif
-#define RT_EXT_LEAF 4             /* reference leaves with more triangles than this get extension records down to this size */
 #endif
 static_assert(RT_NODE_SOFT_MIN > RT_FEED_MARGIN + RT_WAVE && RT_NODE_SOFT_MIN <= RT_NODE_SOFT, "the feed needs room for a mesh above a useful stack height");
 static_assert(RT_LEAF_CAP >= 5 * RT_WAVE, "a node step adds up to 256 leaf items (filter tree: four children) and runs only when 256 slots are free; a fed mesh adds up to 128 on top of 64");
@@ -176,6 +176,9 @@ struct DScene {
     double bmax[3];   /* largest |coordinate| of any box of the scene, per axis (infinity if one is not finite) */
     uint32_t n_tris_total, n_nodes_total; /* array lengths: every index taken from the pool is checked against them */
     uint32_t n_ref_nodes;                 /* records below this index are the reference's; the rest are extension records */
+    int32_t count_own; /* counted kernel variants only: 1 = walk what a production render walks (filter tree first, the
+                          reference's trees for unconfirmed rays) and count that work; 0 = walk and count the reference's
+                          traversal, whose counters equal the CPU checker's */
     int *overflow;    /* bit 0: a push would have passed a stack's capacity; bit 1: an index outside the arrays */
     /* Sphere lists too long for LDS: a tree over the spheres' boxes, in the filter tree's record format (four children per
      * record), that the wave's pool traverses like the triangles' tree; `spheres` is then in that tree's leaf order behind
@@ -247,6 +250,9 @@ struct Cnt {
     uint64_t node_steps, node_lanes, leaf_steps, leaf_lanes, queries, query_lanes;
     uint64_t dbg[8];
     uint64_t sph_tests, sph_nodes; /* exact sphere tests done and sphere-tree nodes visited (per lane, like the public counters) */
+    /* count_own runs: box tests in the reference's double-precision form (undecided single-precision tests, confirmation of a
+     * filter-tree winner) */
+    uint64_t box_exact;
 };
 #define RT_STAMP() ((uint64_t)__builtin_amdgcn_s_memtime())
 #ifndef RT_STAMP_STEPS
@@ -654,7 +660,7 @@ __device__ __forceinline__ void rays_begin2(const DScene &sc, WaveLDS *w, SP sph
  * Both rays go through the same straight-line code so that their loads (triangle, leaf index; then leaf box and
  * object id) are in flight together; a ray without a triangle reads entry 0 and is masked. */
 __device__ __forceinline__ void rays_end(const DScene &sc, WaveLDS *w, int lane, const RayQ &qa, const RayQ &qb, bool own, HitRec &ha, HitRec &hb,
-                                         bool &doubt_a, bool &doubt_b) {
+                                         bool &doubt_a, bool &doubt_b, Cnt *cnt = nullptr) {
     const RayQ *const q[2] = {&qa, &qb};
     HitRec *const h[2] = {&ha, &hb};
     bool doubt[2] = {false, false};
@@ -699,6 +705,7 @@ __device__ __forceinline__ void rays_end(const DScene &sc, WaveLDS *w, int lane,
                 double tlo;
                 box_fast(Box6{(double)lb[r][0], (double)lb[r][1], (double)lb[r][2], (double)lb[r][3], (double)lb[r][4], (double)lb[r][5]}, k, hit, unsure, tlo);
                 if (!hit) doubt[r] = true;
+                if (cnt) cnt->box_exact++; /* a double-precision box test, like the reference's own */
             }
         }
         if (live[r] && !doubt[r]) {
@@ -708,6 +715,7 @@ __device__ __forceinline__ void rays_end(const DScene &sc, WaveLDS *w, int lane,
                 if (r == 0) h[r]->group = group;
                 double lt;
                 if (!ph[r]) (void)tri_eval(T[r], q[r]->C, q[r]->u, h[r]->beta, h[r]->gamma, lt); /* alpha, beta, gamma of the winner (:683-685) */
+                if (cnt && sc.count_own && !ph[r]) cnt->tris++; /* the production count includes this second evaluation */
             }
         }
     }
@@ -726,6 +734,7 @@ __device__ __forceinline__ bool root_test(const DScene &sc, const WaveLDS *w, co
     if (__builtin_expect(unsure, 0)) { /* the ray as ray_begin stored it */
         pass = box_hit_exact(sc.meshes[mesh].root_box, w->ray[0][slot], w->ray[1][slot], w->ray[2][slot], w->ray[3][slot], w->ray[4][slot], w->ray[5][slot]);
         tn = -__builtin_huge_valf();
+        if (CNT) cnt.box_exact++;
     }
     if (CNT && pass) cnt.mesh_calls++;
     fn = lower_float(tn);
@@ -822,6 +831,85 @@ __device__ __forceinline__ void wide_children(const DScene &sc, WaveLDS *w, int 
     children_step<4>(sc, w, lane, have_mask, rl, item_t, bx, code, n_nodes, n_leaves);
 }
 
+/* The NC = 4 / LPR children that lane `sub` of a record's LPR lanes tests: 6 NC consecutive box coordinates and NC codes,
+ * fetched with the widest loads that fit (one lane: the whole 128-byte record). */
+template <int NC>
+__device__ __forceinline__ void load_children(const NodeRec4 *rec, int sub, float (&bx)[6 * NC], uint32_t (&code)[NC]) {
+    if constexpr (NC == 4) {
+        const float4 *rp = reinterpret_cast<const float4 *>(rec);
+        const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3], q4 = rp[4], q5 = rp[5];
+        const uint4 ch = *reinterpret_cast<const uint4 *>(rp + 6);
+        const float b[24] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w,
+                             q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w};
+#pragma unroll
+        for (int a = 0; a < 24; a++) bx[a] = b[a];
+        code[0] = ch.x; code[1] = ch.y; code[2] = ch.z; code[3] = ch.w;
+    } else if constexpr (NC == 2) {
+        const float4 *hp = reinterpret_cast<const float4 *>(rec) + 3 * sub;
+        const float4 h0 = hp[0], h1 = hp[1], h2 = hp[2];
+        const uint2 hc = reinterpret_cast<const uint2 *>(reinterpret_cast<const float4 *>(rec) + 6)[sub];
+        const float b[12] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w, h2.x, h2.y, h2.z, h2.w};
+#pragma unroll
+        for (int a = 0; a < 12; a++) bx[a] = b[a];
+        code[0] = hc.x; code[1] = hc.y;
+    } else {
+        static_assert(NC == 1, "one, two or four lanes per record");
+        const float2 *cp = reinterpret_cast<const float2 *>(rec) + 3 * sub;
+        const float2 c0 = cp[0], c1 = cp[1], c2 = cp[2];
+        bx[0] = c0.x; bx[1] = c0.y; bx[2] = c1.x; bx[3] = c1.y; bx[4] = c2.x; bx[5] = c2.y;
+        code[0] = reinterpret_cast<const uint32_t *>(reinterpret_cast<const float4 *>(rec) + 6)[sub];
+    }
+}
+
+/* One node step on a tree of four-child records (the filter tree, or the tree over a long sphere list): the top k node
+ * items are popped, LPR lanes per record (k <= 64 / LPR), each lane tests 4 / LPR children of its record and pushes those
+ * that its ray may hit (children_step). Branch-free up to the stores, so that all loads of the step are in flight before
+ * the first is waited for: a lane without a record reads item 0 / record 0 and is masked out. */
+template <bool CNT, bool SPHP, int LPR>
+__device__ __forceinline__ void own_node_step(const DScene &sc, WaveLDS *w, const NodeRec4 *tree4, uint32_t n_recs, int lane, int k, int &n_nodes, int &n_leaves,
+                                              Cnt &cnt, uint64_t &st0) {
+    constexpr int NC = 4 / LPR;
+    constexpr int SH = LPR == 4 ? 2 : (LPR == 2 ? 1 : 0);
+    const int li = lane >> SH, sub = lane & (LPR - 1);
+    const unsigned long long in_k = wave_ballot(li < k);
+    const uint2 it = w->node[__builtin_amdgcn_inverse_ballot_w64(in_k) ? n_nodes - 1 - li : 0];
+    n_nodes -= k;
+    wave_sync();
+    const int rl = (int)(it.x >> RT_NODE_BITS);
+    uint32_t rec = it.x & RT_LOW_MASK;
+    if (CNT && RT_STAMP_STEPS && LPR == 1) { asm volatile("" :: "v"(rec)); const uint64_t t = RT_STAMP(); cnt.dbg[0] += t - st0; st0 = t; } /* the item has arrived */
+    /* never fetch outside the arrays: the lanes' answers as one mask, so that the step has no branch that is taken unless
+     * something is wrong */
+    const unsigned long long outside = in_k & wave_ballot(rec >= n_recs);
+    if (__builtin_expect(outside != 0ull, 0)) {
+        if (lane == 0) atomicOr(sc.overflow, 2);
+    }
+    const unsigned long long have_mask = in_k & ~outside;
+    const bool have = __builtin_amdgcn_inverse_ballot_w64(have_mask);
+    if (!have) rec = 0;
+    if (CNT && have) {
+        if (SPHP) cnt.sph_nodes += NC; /* box tests of this lane */
+        else { cnt.box_tests += NC; cnt.nodes += (sub == 0) ? 1 : 0; }
+    }
+    float bx[6 * NC];
+    uint32_t code[NC];
+    load_children<NC>(tree4 + rec, sub, bx, code);
+    if (CNT && RT_STAMP_STEPS && LPR == 1) { /* the record has arrived */
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint64_t t = RT_STAMP(); cnt.dbg[1] += t - st0; st0 = t;
+    }
+#ifdef RT_DIAG_STALE /* diagnostic: popped node items / those that had fallen behind their ray's threshold */
+    if (CNT && !SPHP && LPR == 1) { cnt.dbg[1] += __popcll(__ballot(have)); cnt.dbg[0] += __popcll(__ballot(have && __uint_as_float(it.y) > w->thrf[rl])); }
+#endif
+    children_step<NC>(sc, w, lane, have_mask, rl, __uint_as_float(it.y), bx, code, n_nodes, n_leaves);
+    wave_sync();
+    if (CNT) {
+        const uint64_t t = RT_STAMP();
+        if (SPHP && !RT_STAMP_STEPS) { cnt.dbg[0] += t - st0; cnt.dbg[1]++; cnt.dbg[2] += (uint64_t)k; } /* the sphere tree's share of the node steps */
+        cnt.cyc_node += t - st0; st0 = t; cnt.node_steps++; cnt.node_lanes += (uint64_t)k;
+    }
+}
+
 /* The pool traversal of one query: everything between "the rays' tables are in LDS" (ray_begin) and "the rays' best
  * triangles are in LDS" (rays_end). It takes nothing per lane but the two activity masks and leaves nothing per lane
  * behind: all of its inputs and outputs are the wave's LDS tables. */
@@ -862,10 +950,12 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
             const uint4 ch = *reinterpret_cast<const uint4 *>(rp + 6);
             const float ninf = -__builtin_huge_valf();
             wide_children(sc, w, lane, mask_a, lane, ninf, q0, q1, q2, q3, q4, q5, ch, n_nodes, n_leaves);
+            if (CNT && act_a) { if (SPHP) cnt.sph_nodes += 4; else { cnt.box_tests += 4; cnt.nodes++; } }
             const unsigned long long bb = __ballot(act_b);
             const int nb = __popcll(bb);
             if (n_nodes + 4 * nb <= node_soft && n_leaves + 4 * nb <= RT_LEAF_CAP) {
                 wide_children(sc, w, lane, mask_b, RT_WAVE + lane, ninf, q0, q1, q2, q3, q4, q5, ch, n_nodes, n_leaves);
+                if (CNT && act_b) { if (SPHP) cnt.sph_nodes += 4; else { cnt.box_tests += 4; cnt.nodes++; } }
             } else {
                 if (act_b) w->node[n_nodes + rank_in(bb)] = make_uint2((uint32_t)(RT_WAVE + lane) << RT_NODE_BITS, __float_as_uint(ninf));
                 n_nodes += nb;
@@ -1079,106 +1169,12 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
                 int k = n_nodes < RT_WAVE ? n_nodes : RT_WAVE;
                 const int room = (node_soft - n_nodes) / 3;
                 if (k > room) k = room > 1 ? room : 1;
-#if RT_NARROW_STEP > 1
-                if (k <= RT_WAVE / 4) {
-                    /* a quarter of a step's worth or fewer: four lanes per record, one child each (24 + 4 bytes) */
-                    const int li = lane >> 2, sub = lane & 3;
-                    const unsigned long long in_k4 = wave_ballot(li < k);
-                    const uint2 it4 = w->node[__builtin_amdgcn_inverse_ballot_w64(in_k4) ? n_nodes - 1 - li : 0];
-                    n_nodes -= k;
-                    wave_sync();
-                    const int rl4 = (int)(it4.x >> RT_NODE_BITS);
-                    uint32_t rec4 = it4.x & RT_LOW_MASK;
-                    const unsigned long long outside4 = in_k4 & wave_ballot(rec4 >= n_recs);
-                    if (__builtin_expect(outside4 != 0ull, 0)) {
-                        if (lane == 0) atomicOr(sc.overflow, 2);
-                    }
-                    const unsigned long long have4 = in_k4 & ~outside4;
-                    if (!__builtin_amdgcn_inverse_ballot_w64(have4)) rec4 = 0;
-                    if (CNT && SPHP && __builtin_amdgcn_inverse_ballot_w64(have4)) cnt.sph_nodes += 1;
-                    const float2 *cp = reinterpret_cast<const float2 *>(tree4 + rec4) + 3 * sub;
-                    const float2 c0 = cp[0], c1 = cp[1], c2 = cp[2];
-                    const uint32_t cc = reinterpret_cast<const uint32_t *>(reinterpret_cast<const float4 *>(tree4 + rec4) + 6)[sub];
-                    const float cb[6] = {c0.x, c0.y, c1.x, c1.y, c2.x, c2.y};
-                    const uint32_t ccode[1] = {cc};
-                    children_step<1>(sc, w, lane, have4, rl4, __uint_as_float(it4.y), cb, ccode, n_nodes, n_leaves);
-                    wave_sync();
-                    if (CNT) {
-                        uint64_t t = RT_STAMP();
-                        if (SPHP && !RT_STAMP_STEPS) { cnt.dbg[0] += t - st0; cnt.dbg[1]++; cnt.dbg[2] += (uint64_t)k; }
-                        cnt.cyc_node += t - st0; st0 = t; cnt.node_steps++; cnt.node_lanes += (uint64_t)k;
-                    }
-                    continue;
-                }
-#endif
-#if RT_NARROW_STEP
-                if (k <= RT_WAVE / 2) {
-                    /* Half a step's worth of records or fewer: two lanes share a record, each tests two of its children
-                     * (their boxes are 48 consecutive bytes, their codes 8) - half the arithmetic and half the pushes per
-                     * lane in the steps that end a query. */
-                    const int li = lane >> 1, sub = lane & 1;
-                    const unsigned long long in_k2 = wave_ballot(li < k);
-                    const uint2 it2 = w->node[__builtin_amdgcn_inverse_ballot_w64(in_k2) ? n_nodes - 1 - li : 0];
-                    n_nodes -= k;
-                    wave_sync();
-                    const int rl2 = (int)(it2.x >> RT_NODE_BITS);
-                    uint32_t rec2 = it2.x & RT_LOW_MASK;
-                    const unsigned long long outside2 = in_k2 & wave_ballot(rec2 >= n_recs);
-                    if (__builtin_expect(outside2 != 0ull, 0)) {
-                        if (lane == 0) atomicOr(sc.overflow, 2);
-                    }
-                    const unsigned long long have2 = in_k2 & ~outside2;
-                    if (!__builtin_amdgcn_inverse_ballot_w64(have2)) rec2 = 0;
-                    if (CNT && SPHP && __builtin_amdgcn_inverse_ballot_w64(have2)) cnt.sph_nodes += 2; /* two box tests per lane */
-                    const float4 *hp = reinterpret_cast<const float4 *>(tree4 + rec2) + 3 * sub;
-                    const float4 h0 = hp[0], h1 = hp[1], h2 = hp[2];
-                    const uint2 hc = reinterpret_cast<const uint2 *>(reinterpret_cast<const float4 *>(tree4 + rec2) + 6)[sub];
-                    const float hb[12] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w, h2.x, h2.y, h2.z, h2.w};
-                    const uint32_t hcode[2] = {hc.x, hc.y};
-                    children_step<2>(sc, w, lane, have2, rl2, __uint_as_float(it2.y), hb, hcode, n_nodes, n_leaves);
-                    wave_sync();
-                    if (CNT) {
-                        uint64_t t = RT_STAMP();
-                        if (SPHP && !RT_STAMP_STEPS) { cnt.dbg[0] += t - st0; cnt.dbg[1]++; cnt.dbg[2] += (uint64_t)k; }
-                        cnt.cyc_node += t - st0; st0 = t; cnt.node_steps++; cnt.node_lanes += (uint64_t)k;
-                    }
-                    continue;
-                }
-#endif
-                const unsigned long long in_k = wave_ballot(lane < k);
-                const uint2 it = w->node[__builtin_amdgcn_inverse_ballot_w64(in_k) ? n_nodes - 1 - lane : 0];
-                n_nodes -= k;
-                wave_sync();
-                const int rl = (int)(it.x >> RT_NODE_BITS);
-                uint32_t rec = it.x & RT_LOW_MASK;
-                if (CNT && RT_STAMP_STEPS) { asm volatile("" :: "v"(rec)); const uint64_t t = RT_STAMP(); cnt.dbg[0] += t - st0; st0 = t; } /* the item has arrived */
-                /* never fetch outside the arrays: the lanes' answers as one mask, so that the step has no branch that is
-                 * taken unless something is wrong */
-                const unsigned long long outside = in_k & wave_ballot(rec >= n_recs);
-                if (__builtin_expect(outside != 0ull, 0)) {
-                    if (lane == 0) atomicOr(sc.overflow, 2);
-                }
-                const unsigned long long have_mask = in_k & ~outside;
-                const bool have = __builtin_amdgcn_inverse_ballot_w64(have_mask);
-                if (!have) rec = 0;
-                if (CNT && SPHP && have) cnt.sph_nodes += 4; /* four box tests per record */
-                const float4 *rp = reinterpret_cast<const float4 *>(tree4 + rec);
-                const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3], q4 = rp[4], q5 = rp[5];
-                const uint4 ch = *reinterpret_cast<const uint4 *>(rp + 6);
-                if (CNT && RT_STAMP_STEPS) { /* the record has arrived */
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    const uint64_t t = RT_STAMP(); cnt.dbg[1] += t - st0; st0 = t;
-                }
-#ifdef RT_DIAG_STALE /* diagnostic: popped node items / those that had fallen behind their ray's threshold */
-                if (CNT && !SPHP) { cnt.dbg[1] += __popcll(__ballot(have)); cnt.dbg[0] += __popcll(__ballot(have && __uint_as_float(it.y) > w->thrf[rl])); }
-#endif
-                wide_children(sc, w, lane, have_mask, rl, __uint_as_float(it.y), q0, q1, q2, q3, q4, q5, ch, n_nodes, n_leaves);
-                wave_sync();
-                if (CNT) {
-                    uint64_t t = RT_STAMP();
-                    if (SPHP && !RT_STAMP_STEPS) { cnt.dbg[0] += t - st0; cnt.dbg[1]++; cnt.dbg[2] += (uint64_t)k; } /* the sphere tree's share of the node steps */
-                    cnt.cyc_node += t - st0; st0 = t; cnt.node_steps++; cnt.node_lanes += (uint64_t)k;
-                }
+                /* Half a step's worth of records or fewer: two lanes share a record, each tests two of its children (their
+                 * boxes are 48 consecutive bytes, their codes 8); a quarter or fewer: four lanes, one child each (24 + 4
+                 * bytes) - half or a quarter of the arithmetic and pushes per lane in the steps that end a query. */
+                if (RT_NARROW_STEP > 1 && k <= RT_WAVE / 4) own_node_step<CNT, SPHP, 4>(sc, w, tree4, n_recs, lane, k, n_nodes, n_leaves, cnt, st0);
+                else if (RT_NARROW_STEP > 0 && k <= RT_WAVE / 2) own_node_step<CNT, SPHP, 2>(sc, w, tree4, n_recs, lane, k, n_nodes, n_leaves, cnt, st0);
+                else own_node_step<CNT, SPHP, 1>(sc, w, tree4, n_recs, lane, k, n_nodes, n_leaves, cnt, st0);
             } else {
                 /* Up to 64 BVH records per step, one per lane: both child boxes are tested (raytracer.cpp:656-665)
                  * and the children that are hit are pushed. 64 records are popped while the stack is below
@@ -1206,7 +1202,7 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
                 const RayKf rk = ray_k_from_lds(w, rl);
                 have = have && !(__uint_as_float(it.y) > thr); /* fallen behind the threshold since it was pushed */
                 const bool ext = rec >= sc.n_ref_nodes; /* a filter of this implementation, not a record of the reference */
-                if (CNT && have && !ext) { cnt.nodes++; cnt.box_tests += 2; }
+                if (CNT && have && (!ext || sc.count_own)) { cnt.nodes++; cnt.box_tests += 2; } /* the reference has no extension records */
                 int32_t L = __float_as_int(q3.x), R = __float_as_int(q3.y);
                 const int32_t nL = __float_as_int(q3.z), nR = __float_as_int(q3.w);
                 bool hl, hr, ul, ur;
@@ -1222,6 +1218,7 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
                     const double ux = w->ray[3][rl], uy = w->ray[4][rl], uz = w->ray[5][rl];
                     if (ul) { hl = box_hit_exact(sc.halves[(size_t)rec * 2].box, cx, cy, cz, ux, uy, uz); tl = -__builtin_huge_valf(); }
                     if (ur) { hr = box_hit_exact(sc.halves[(size_t)rec * 2 + 1].box, cx, cy, cz, ux, uy, uz); tr = -__builtin_huge_valf(); }
+                    if (CNT) cnt.box_exact += (uint64_t)((ul ? 1 : 0) + (ur ? 1 : 0));
                 }
                 hl = have && hl && !(tl > thr);
                 hr = have && hr && !(tr > thr);
@@ -1349,11 +1346,7 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScen
     /* First on the filter tree (one tree over all meshes; not for the counted variant or RT_F_NO_PRUNE, which
      * reproduce the reference's traversal); the rays whose winner could not be confirmed go round again on the
      * reference's trees. */
-#ifdef RT_DIAG_OWN /* diagnostic build: the counted variant also runs on the filter tree (its counters then differ from the reference's) */
-    bool own = prune && sc.own_rec4 != nullptr;
-#else
-    bool own = !CNT && prune && sc.own_rec4 != nullptr;
-#endif
+    bool own = (!CNT || sc.count_own) && prune && sc.own_rec4 != nullptr;
     HitRec kept_a = {}, kept_b = {};
     bool kept = false, redo_a = false, redo_b = false;
   for (;;) {
@@ -1383,7 +1376,7 @@ __device__ __forceinline__ void scene_closest_wave(const DScene &sc, const DScen
 #endif
     }
     bool da, db;
-    rays_end(cold, w, lane, qa, qb, own, ha, hb, da, db);
+    rays_end(cold, w, lane, qa, qb, own, ha, hb, da, db, CNT ? &cnt : nullptr);
     wave_sync();
     if (!own || __ballot(da || db) == 0ull) break;
     if (CNT) { cnt.dbg[6] += (uint64_t)(__popcll(__ballot(da)) + __popcll(__ballot(db))); cnt.dbg[7]++; }
@@ -1869,9 +1862,9 @@ __device__ __forceinline__ void flush_counters(const Cnt &c, rt_counters *out) {
         for (int q = 0; q < 12; q++) atomicAdd(o + 8 + q, (unsigned long long)d[q]);
         for (int q = 0; q < 8; q++) atomicAdd(o + 20 + q, (unsigned long long)c.dbg[q]);
     }
-    uint64_t e[2] = {c.sph_tests, c.sph_nodes};
+    uint64_t e[3] = {c.sph_tests, c.sph_nodes, c.box_exact};
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
+    for (int q = 0; q < 3; q++) {
         uint64_t x = e[q];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_xor((unsigned long long)x, off, 64);
         if ((threadIdx.x & 63) == 0 && x) atomicAdd(o + 28 + q, (unsigned long long)x);

@@ -13,7 +13,7 @@
 
 using namespace rtd;
 
-#define RT_COUNTER_WORDS 30 /* rt_counters (8 words) + 22 diagnostic words of rt_device.hip.h */
+#define RT_COUNTER_WORDS 32 /* rt_counters (8 words) + 23 diagnostic words of rt_device.hip.h (+ 1 spare) */
 #define RT_BLOCK 64 /* one workgroup = one wave: the LDS pool of rt_device.hip.h is per wave */
 #ifndef RT_WAVES_PER_SIMD
 #define RT_WAVES_PER_SIMD 2 /* resident waves per SIMD the render kernel is compiled for (register budget 512 / this) */

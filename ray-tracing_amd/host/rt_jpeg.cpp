@@ -156,9 +156,9 @@ struct Decoder {
         const int t = decode(hdc[c.hd]);
         memset(data, 0, 64 * sizeof(int16_t));
         const int diff = t ? receive_extend(t) : 0;
-        const int dc = c.dc_pred + diff;
+        const int dc = (int)((uint32_t)c.dc_pred + (uint32_t)diff); /* wraps on a corrupt stream instead of overflowing */
         c.dc_pred = dc;
-        data[0] = (int16_t)(dc * dq[0]);
+        data[0] = (int16_t)((uint32_t)dc * (uint32_t)dq[0]);
         int k = 1;
         do {
             const int rs = decode(hac[c.ha]);
@@ -180,9 +180,9 @@ struct Decoder {
             memset(data, 0, 64 * sizeof(int16_t));
             const int t = decode(hdc[c.hd]);
             const int diff = t ? receive_extend(t) : 0;
-            const int dc = c.dc_pred + diff;
+            const int dc = (int)((uint32_t)c.dc_pred + (uint32_t)diff);
             c.dc_pred = dc;
-            data[0] = (int16_t)(dc * (1 << succ_low));
+            data[0] = (int16_t)((uint32_t)dc << succ_low);
         } else if (bit()) {
             data[0] = (int16_t)(data[0] + (int16_t)(1 << succ_low));
         }
@@ -395,8 +395,21 @@ struct Decoder {
             if (c.h > h_max) h_max = c.h;
             if (c.v > v_max) v_max = c.v;
         }
+        /* the up-sampling below repeats or interpolates whole samples: a component's factors must divide the largest ones
+         * (with h_max / h rounded down a row would be read past its end) */
+        for (int i = 0; i < n_comp; i++)
+            if (h_max % comp[i].h != 0 || v_max % comp[i].v != 0) bad("bad sampling factors");
         mcu_x = (W + h_max * 8 - 1) / (h_max * 8);
         mcu_y = (H + v_max * 8 - 1) / (v_max * 8);
+        /* Before anything is allocated: the picture must be of a size this decoder is meant for, and the file long enough to
+         * hold it - every 8x8 block of every component takes at least one bit of entropy-coded data (a header of thirty
+         * bytes must not make the decoder touch gigabytes). */
+        if ((uint64_t)W * (uint64_t)H > (1ull << 28)) bad("picture too large");
+        {
+            uint64_t blocks = 0;
+            for (int i = 0; i < n_comp; i++) blocks += (uint64_t)mcu_x * mcu_y * comp[i].h * comp[i].v;
+            if (blocks > (uint64_t)(end - p) * 8) bad("file too short for its picture size");
+        }
         for (int i = 0; i < n_comp; i++) {
             Component &c = comp[i];
             c.x = (W * c.h + h_max - 1) / h_max;

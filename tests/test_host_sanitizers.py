@@ -55,6 +55,26 @@ def test_jpeg_decoder_on_mutated_files(tmp_path):
     out = subprocess.run([exe] + files, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert out.stdout.startswith("decoded ")
+    # Fixed cases the mutations do not reach. (1) Sampling factors that do not divide the largest one: a 4:2:0 file whose Cb
+    # component claims h = 3 - up-sampling by h_max / h = 1 would read a full-width row from a half-width plane.
+    # (2) A short file that declares a 65535 x 65535 picture: refused before any plane is allocated.
+    a = (rng.random((16, 24, 3)) * 255).astype(np.uint8)
+    fn = str(tmp_path / "sub420.jpg")
+    PIL.fromarray(a).save(fn, "JPEG", quality=80, subsampling=2)
+    raw = bytearray(open(fn, "rb").read())
+    sof = raw.index(b"\xff\xc0")
+    assert raw[sof + 9] == 3 and raw[sof + 11] == 0x22 and raw[sof + 14] == 0x11  # three components, Y 2x2, Cb 1x1
+    bad_factors = bytearray(raw)
+    bad_factors[sof + 14] = 0x31
+    huge = bytearray(raw)
+    huge[sof + 5:sof + 9] = b"\xff\xff\xff\xff"
+    cases = []
+    for name, data in (("bad_factors.jpg", bad_factors), ("huge.jpg", huge)):
+        cases.append(str(tmp_path / name))
+        open(cases[-1], "wb").write(bytes(data))
+    out = subprocess.run([exe] + cases, env=dict(env, EXPECT_REFUSED="1"), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "bad sampling factors" in out.stdout and ("too large" in out.stdout or "too short" in out.stdout)
 
 
 def test_obj_reader_on_mutated_files(tmp_path):

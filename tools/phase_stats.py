@@ -12,7 +12,7 @@ else:
     s, cam, fl, meta = scenes.battle(W=W)
 r = rta.Renderer(0); r.upload(s); r.accum_clear(W, W); r.reset_counters()
 r.render(cam, rta.make_params(W, W, spp, flags=fl | rta.RT_F_COUNTERS)); r.sync()
-c = r.counters(); d = (C.c_uint64 * 22)(); rta.lib.rt_debug_stats(r._h, d)
+c = r.counters(); d = (C.c_uint64 * 24)(); rta.lib.rt_debug_stats(r._h, d)
 dbg = [int(x) for x in d][12:20]
 names = ["cyc_fresh", "cyc_roots", "cyc_node", "cyc_leaf", "cyc_finish", "cyc_shade", "node_steps", "node_lanes", "leaf_steps", "leaf_lanes", "queries", "query_lanes"]
 d = dict(zip(names, [int(x) for x in d]))
