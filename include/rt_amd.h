@@ -248,7 +248,10 @@ double *rt_accum_device_ptr(rt_ctx *ctx);
  * indices (rt_params.spp_offset) of every pixel, the reference's "rows in parallel" (raytracer.cpp:1456) turned into
  * "samples in parallel" - for callers that drive several GPUs from threads of one process; processes-per-GPU callers
  * sum with RCCL instead. Waits for src's renders, returns when the sum is in dst. Adding the contexts in a fixed order
- * gives run-to-run identical bits. */
+ * gives run-to-run identical bits. Two GPUs without peer access to each other (hipDeviceCanAccessPeer), or a peer copy
+ * that the runtime refuses, are served through a pinned host buffer instead. The calling thread's current HIP device is
+ * the same after the call as before it, also when the call fails; a failure is reported on dst (rt_last_error(dst))
+ * with the HIP error's text. No other thread may use src (render into it, clear or destroy it) during the call. */
 int rt_accum_add(rt_ctx *dst, rt_ctx *src);
 
 /* Replaces raytracer.cpp:1488-1501: colour/spp_total, pow(.,0.45), min(255,.),

@@ -65,6 +65,13 @@ int rth_scene_upload(rth_scene *s, rt_ctx *ctx, int64_t *flat_bytes);
  * tone-mapped there; rgb8 receives W*H*3 bytes. Replaces the OpenMP pixel loop raytracer.cpp:1456-1503. */
 int rth_scene_render_devices(rth_scene *s, const rt_camera *cam, const rt_params *p, const int32_t *devices, int32_t n_devices, uint8_t *rgb8);
 int rth_scene_flat_info(rth_scene *s, int64_t *n_spheres, int64_t *n_meshes, int64_t *n_nodes, int64_t *n_tris, int64_t *bytes);
+/* The flattened scene itself - the arrays of rt_scene_desc (rt_amd.h) exactly as rth_scene_upload hands them to
+ * rt_upload_scene: spheres and meshes in object order (raytracer.cpp:1401-1435), one rt_bvh_node per inner Noeud
+ * (:190-196), triangles and attributes in the reference's visiting order (:656-670), the textures' texels as
+ * stbi_load returned them (:762). Each pointer may be NULL; the others receive the counts of rth_scene_flat_info
+ * (n_tex textures, texel_bytes bytes of texels: call once with NULL arrays to size them). */
+int rth_scene_flat_arrays(rth_scene *s, rt_sphere *spheres, rt_mesh *meshes, rt_bvh_node *nodes, rt_tri *tris, rt_tri_attr *attrs, rt_texture *tex,
+                          uint8_t *texels, int64_t *n_tex, int64_t *texel_bytes);
 
 /* camera basis as main() builds it (raytracer.cpp:1441-1453) and the literals of the render loop */
 int rth_camera_make(const double C[3], double fov_deg, double angle_v_deg, double angle_h_deg, int32_t W, double focus, double aa_sigma,

@@ -58,10 +58,18 @@ RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt
 RTH_SYMBOLS = ["rth_last_error", "rth_mesh_create", "rth_mesh_destroy", "rth_mesh_read_obj", "rth_mesh_load_texture",
                "rth_mesh_add_texture", "rth_mesh_texture", "rth_decode_jpeg", "rth_mesh_set_raw", "rth_mesh_op", "rth_mesh_build_bvh", "rth_mesh_build_bvh_device", "rth_mesh_sizes",
                "rth_mesh_get", "rth_mesh_bvh_dump", "rth_scene_create", "rth_scene_destroy", "rth_scene_add_sphere",
-               "rth_scene_add_mesh", "rth_scene_upload", "rth_scene_render_devices", "rth_scene_flat_info", "rth_camera_make", "rth_params_default",
+               "rth_scene_add_mesh", "rth_scene_upload", "rth_scene_render_devices", "rth_scene_flat_info", "rth_scene_flat_arrays", "rth_camera_make", "rth_params_default",
                "rth_write_png", "rth_write_execution_time"]
 
 _vp, _i32, _i64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+# the little-endian PODs of include/rt_amd.h as numpy record types
+SPHERE_DTYPE = np.dtype([("O", "f8", 3), ("R", "f8"), ("albedo", "f8", 3), ("flags", "i4"), ("object_id", "i4")])
+NODE_DTYPE = np.dtype([("boxL", "f8", 6), ("boxR", "f8", 6), ("L", "i4"), ("R", "i4"), ("nL", "i4"), ("nR", "i4"), ("pad", "i4", 4)])
+TRI_DTYPE = np.dtype([("A", "f8", 3), ("e1", "f8", 3), ("e2", "f8", 3), ("orig_id", "i4"), ("mesh", "i4")])
+ATTR_DTYPE = np.dtype([("n", "f8", (3, 3)), ("uv", "f8", (3, 2)), ("group", "i4"), ("pad", "i4")])
+MESH_DTYPE = np.dtype([("root_box", "f8", 6), ("albedo", "f8", 3), ("flags", "i4"), ("object_id", "i4"), ("root", "i4"), ("root_count", "i4"),
+                       ("first_tex", "i4"), ("n_tex", "i4"), ("first_tri", "i4"), ("n_tris", "i4"), ("max_depth", "i4"), ("pad", "i4")])
+TEX_DTYPE = np.dtype([("offset", "i8"), ("W", "i4"), ("H", "i4")])
 _pd = C.POINTER(C.c_double)
 
 
@@ -116,6 +124,7 @@ _sig("rth_scene_add_mesh", C.c_int, _vp, _vp)
 _sig("rth_scene_upload", C.c_int, _vp, _vp, C.POINTER(_i64))
 _sig("rth_scene_render_devices", C.c_int, _vp, C.POINTER(rt_camera), C.POINTER(rt_params), _vp, _i32, _vp)
 _sig("rth_scene_flat_info", C.c_int, _vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64))
+_sig("rth_scene_flat_arrays", C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64))
 _sig("rth_camera_make", C.c_int, _pd, _dbl, _dbl, _dbl, _i32, _dbl, _dbl, _dbl, C.POINTER(rt_camera))
 _sig("rth_params_default", C.c_int, _i32, _i32, _i32, C.POINTER(rt_params))
 _sig("rth_write_png", C.c_int, C.c_char_p, _i32, _i32, _vp)
@@ -286,6 +295,22 @@ class Scene:
             else:
                 lib.rth_scene_add_mesh(h, o._h)
         return h
+
+    def flat_arrays(self):
+        """the flattened scene as numpy record arrays with the layouts of rt_amd.h (what upload() hands to rt_upload_scene)"""
+        info = self.flat_info()
+        h = self._build_handle()
+        try:
+            nt, nb = _i64(), _i64()
+            _host_check(lib.rth_scene_flat_arrays(h, None, None, None, None, None, None, None, C.byref(nt), C.byref(nb)))
+            out = dict(spheres=np.zeros(info["n_spheres"], SPHERE_DTYPE), meshes=np.zeros(info["n_meshes"], MESH_DTYPE),
+                       nodes=np.zeros(info["n_nodes"], NODE_DTYPE), tris=np.zeros(info["n_tris"], TRI_DTYPE),
+                       attrs=np.zeros(info["n_tris"], ATTR_DTYPE), tex=np.zeros(nt.value, TEX_DTYPE), texels=np.zeros(nb.value, np.uint8))
+            _host_check(lib.rth_scene_flat_arrays(h, *[C.c_void_p(out[k].ctypes.data) for k in ("spheres", "meshes", "nodes", "tris", "attrs", "tex", "texels")],
+                                                  None, None))
+            return out
+        finally:
+            lib.rth_scene_destroy(h)
 
     def flat_info(self):
         h = self._build_handle()

@@ -185,6 +185,9 @@ struct rt_ctx {
     size_t d_rgb_bytes = 0;
     double *d_peer = nullptr;    /* rt_accum_add: another context's accumulator, copied here before it is added */
     size_t d_peer_bytes = 0;
+    double *h_bounce = nullptr;  /* rt_accum_add without peer access: pinned host buffer the sums pass through */
+    size_t h_bounce_bytes = 0;
+    bool force_host_bounce = false;
     unsigned char *static_scratch = nullptr; /* this device's copy of `scratch` (hipGetSymbolAddress at rt_create) */
     int n_cus = 256;
     int waves_per_cu = 8;
@@ -266,7 +269,12 @@ static int check_overflow(rt_ctx *c) {
 
 extern "C" {
 
-const char *rt_version(void) { return "rt_amd 0.1 (gfx950, fp64, -ffp-contract=off)"; }
+#ifndef RT_BUILD_SCHED
+#define RT_BUILD_SCHED "default"
+#endif
+/* names the instruction scheduler the render kernels were compiled with (csrc/Makefile falls back to the default one if the
+ * compiler fails with the preferred one) */
+const char *rt_version(void) { return "rt_amd 0.1 (gfx950, fp64, -ffp-contract=off, scheduler " RT_BUILD_SCHED ")"; }
 
 int rt_create(int device, rt_ctx **out) {
     if (!out) return fail(nullptr, RT_E_INVALID, "rt_create: out is NULL");
@@ -322,6 +330,7 @@ void rt_destroy(rt_ctx *c) {
     if (c->d_next_slot) (void)hipFree(c->d_next_slot);
     if (c->d_tone) (void)hipFree(c->d_tone);
     if (c->d_peer) (void)hipFree(c->d_peer);
+    if (c->h_bounce) (void)hipHostFree(c->h_bounce);
     if (c->d_rgb) (void)hipFree(c->d_rgb);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1053,6 +1062,15 @@ int rt_accum_upload(rt_ctx *c, const double *host_in, int64_t n) {
     return RT_OK;
 }
 
+/* restores the calling thread's current device when a function that switches it returns, on every path */
+namespace {
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); } }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+} // namespace
+
 int rt_accum_add(rt_ctx *dst, rt_ctx *src) {
     if (!dst || !src) return RT_E_INVALID;
     if (dst == src) return fail(dst, RT_E_INVALID, "rt_accum_add: a context cannot be added to itself");
@@ -1060,6 +1078,7 @@ int rt_accum_add(rt_ctx *dst, rt_ctx *src) {
         return fail(dst, RT_E_STATE, "rt_accum_add: both contexts need their own accumulator of the same size (rt_accum_clear)");
     const int64_t n = (int64_t)dst->accW * dst->accH * 3;
     const size_t nb = (size_t)n * sizeof(double);
+    DeviceGuard guard; /* the caller's current device is the same after the call, whatever happens */
     /* the source's renders must have finished before its accumulator is read from another stream */
     HIPCHK(dst, hipSetDevice(src->device));
     HIPCHK(dst, hipStreamSynchronize(src->stream));
@@ -1069,14 +1088,48 @@ int rt_accum_add(rt_ctx *dst, rt_ctx *src) {
         if (dst->d_peer) (void)hipFree(dst->d_peer);
         dst->d_peer = nullptr;
         dst->d_peer_bytes = 0;
-        if (hipMalloc((void **)&dst->d_peer, nb) != hipSuccess) return fail(dst, RT_E_NOMEM, "rt_accum_add: staging buffer allocation failed");
+        if (hipMalloc((void **)&dst->d_peer, nb) != hipSuccess) { (void)hipGetLastError(); return fail(dst, RT_E_NOMEM, "rt_accum_add: staging buffer allocation failed"); }
         dst->d_peer_bytes = nb;
     }
-    /* over xGMI when the two contexts sit on different GPUs, a device-to-device copy when they share one */
-    HIPCHK(dst, hipMemcpyPeerAsync(dst->d_peer, dst->device, src->accum, src->device, nb, dst->stream));
+    /* How the source's sums get into dst's staging buffer: a device-to-device copy when the contexts share a GPU; over xGMI
+     * (hipMemcpyPeerAsync) when they sit on two GPUs that can reach each other; otherwise - the runtime refuses peer access
+     * (another root complex, a restricted container), or the peer copy itself fails - through a pinned host buffer. */
+    bool direct = true;
+    if (dst->force_host_bounce) direct = false;
+    else if (src->device != dst->device) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, dst->device, src->device) != hipSuccess) { can = 0; (void)hipGetLastError(); }
+        direct = can != 0;
+    }
+    if (direct) {
+        const hipError_t e = hipMemcpyPeerAsync(dst->d_peer, dst->device, src->accum, src->device, nb, dst->stream);
+        if (e != hipSuccess) { (void)hipGetLastError(); direct = false; } /* nothing was queued: take the other way */
+    }
+    if (!direct) {
+        if (dst->h_bounce_bytes < nb) {
+            if (dst->h_bounce) (void)hipHostFree(dst->h_bounce);
+            dst->h_bounce = nullptr;
+            dst->h_bounce_bytes = 0;
+            if (hipHostMalloc((void **)&dst->h_bounce, nb, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return fail(dst, RT_E_NOMEM, "rt_accum_add: pinned host buffer allocation failed"); }
+            dst->h_bounce_bytes = nb;
+        }
+        HIPCHK(dst, hipSetDevice(src->device));
+        HIPCHK(dst, hipMemcpyAsync(dst->h_bounce, src->accum, nb, hipMemcpyDeviceToHost, src->stream));
+        HIPCHK(dst, hipStreamSynchronize(src->stream));
+        HIPCHK(dst, hipSetDevice(dst->device));
+        HIPCHK(dst, hipMemcpyAsync(dst->d_peer, dst->h_bounce, nb, hipMemcpyHostToDevice, dst->stream));
+    }
     hipLaunchKernelGGL(rt_accum_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, dst->stream, dst->accum, dst->d_peer, n);
     HIPCHK(dst, hipGetLastError());
     HIPCHK(dst, hipStreamSynchronize(dst->stream)); /* the caller may clear or destroy src as soon as this returns */
+    return RT_OK;
+}
+
+/* not part of the public header: rt_accum_add into this context goes through the pinned host buffer even where a direct
+ * copy is possible (tests: the fallback path on a machine with one GPU) */
+int rt_debug_force_host_bounce(rt_ctx *c, int on) {
+    if (!c) return RT_E_INVALID;
+    c->force_host_bounce = on != 0;
     return RT_OK;
 }
 

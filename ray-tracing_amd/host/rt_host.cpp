@@ -624,13 +624,19 @@ void renderDevices(const rt_scene_desc &d, const rt_camera &cam, const rt_params
         if (rp.spp > 0 && rt_render(x, &cam, &rp, nullptr) != RT_OK) { bad("rt_render", x); return; }
         if (rt_sync(x) != RT_OK) bad("rt_sync", x);
     };
+    std::string first_err;
     {
+        /* whatever fails - a device that cannot be opened, a thread that cannot be started - the threads already running
+         * are joined and every context that was created is destroyed before the error is reported */
         std::vector<std::thread> th;
-        for (int k = 1; k < n; k++) th.emplace_back(work, k);
-        work(0);
+        try {
+            for (int k = 1; k < n; k++) th.emplace_back(work, k);
+            work(0);
+        } catch (const std::exception &e) {
+            first_err = std::string("renderDevices: ") + e.what();
+        }
         for (auto &t : th) t.join();
     }
-    std::string first_err;
     for (int k = 0; k < n && first_err.empty(); k++) first_err = err[(size_t)k];
     for (int k = 1; k < n && first_err.empty(); k++) /* fixed order: the same bits from run to run */
         if (rt_accum_add(ctx[0], ctx[(size_t)k]) != RT_OK) first_err = std::string("rt_accum_add: ") + rt_last_error(ctx[0]);
@@ -912,6 +918,23 @@ int rth_scene_flat_info(rth_scene *s, int64_t *n_spheres, int64_t *n_meshes, int
         if (n_nodes) *n_nodes = (int64_t)fs.nodes.size();
         if (n_tris) *n_tris = (int64_t)fs.tris.size();
         if (bytes) *bytes = (int64_t)fs.bytes();
+    })
+}
+
+int rth_scene_flat_arrays(rth_scene *s, rt_sphere *spheres, rt_mesh *meshes, rt_bvh_node *nodes, rt_tri *tris, rt_tri_attr *attrs, rt_texture *tex,
+                          uint8_t *texels, int64_t *n_tex, int64_t *texel_bytes) {
+    RTH_TRY({
+        rt::FlatScene fs;
+        rt::flatten(s->s, fs);
+        if (n_tex) *n_tex = (int64_t)fs.tex.size();
+        if (texel_bytes) *texel_bytes = (int64_t)fs.texels.size();
+        if (spheres) memcpy(spheres, fs.spheres.data(), fs.spheres.size() * sizeof(rt_sphere));
+        if (meshes) memcpy(meshes, fs.meshes.data(), fs.meshes.size() * sizeof(rt_mesh));
+        if (nodes) memcpy(nodes, fs.nodes.data(), fs.nodes.size() * sizeof(rt_bvh_node));
+        if (tris) memcpy(tris, fs.tris.data(), fs.tris.size() * sizeof(rt_tri));
+        if (attrs) memcpy(attrs, fs.attrs.data(), fs.attrs.size() * sizeof(rt_tri_attr));
+        if (tex) memcpy(tex, fs.tex.data(), fs.tex.size() * sizeof(rt_texture));
+        if (texels) memcpy(texels, fs.texels.data(), fs.texels.size());
     })
 }
 

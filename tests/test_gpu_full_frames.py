@@ -1,0 +1,76 @@
+"""GPU: the two small configurations of the benchmark at their full size, built exactly as bench.py builds them.
+cfg1 (sphere room, point light + hard shadows of raytracer.cpp:1040-1055, mirror, refraction, un-jittered camera ray
+:1482, 512 x 512 @ 1 spp = 262 144 deterministic paths): the whole accumulator against the CPU oracle's pixel loop and
+the tone-mapped bytes (:1488-1501). cfg3 (textured 54 320-triangle mesh with a 1024 x 1024 texture on a mirror floor,
+512 x 512): every primary ray's object, triangle and t bit for bit, and a 48 x 48 tile of per-sample radiance with the
+path traces."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench_config(name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rt_bench_script", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.CONFIGS[name]
+
+
+def test_cfg1_full_frame(gpu, rta, scenes, ob):
+    builder, kw, size, spp_step, spp_image, _, _ = _bench_config("cfg1")
+    assert (size, spp_step, spp_image) == (512, 1, 1)
+    W = size
+    s, cam, flags = getattr(scenes, builder)(W=W, **kw)[:3]
+    orc = ob.OracleScene(scenes.export_objects(s), s.I, s.L, math="portable")
+    gpu.upload(s)
+    p = rta.make_params(W, W, 1, flags=flags)
+    gpu.accum_clear(W, W)
+    gpu.render(cam, p)
+    g = gpu.accum_download(W, W)
+    o = orc.render(cam, p)
+    assert o.shape == (W, W, 3) and o.max() > 1e3 and (o > 0).mean() > 0.5
+    rel = np.abs(g - o) / np.maximum(np.abs(o), 1e-6)
+    assert rel.max() < 1e-4, rel.max()  # the stated bar for deterministic paths
+    assert rel.max() < 1e-12, rel.max()  # what is measured
+    assert np.array_equal(gpu.resolve(W, W, 1), ob.resolve(o, 1))
+
+
+class TestCfg3Full:
+    @pytest.fixture(scope="class")
+    def full(self, gpu, scenes):
+        builder, kw, size, _, _, _, _ = _bench_config("cfg3")
+        assert builder == "mesh_room" and kw == {"n_tris": 54320, "tex_size": 1024} and size == 512
+        out = getattr(scenes, builder)(W=size, **kw)
+        gpu.upload(out[0])
+        return out[0], out[1], out[2], size
+
+    def test_all_primary_rays(self, gpu, rta, scenes, ob, full):
+        s, cam, flags, W = full
+        info = s.flat_info()
+        assert info["n_tris"] == 54320
+        orc = ob.OracleScene(scenes.export_objects(s), s.I, s.L)
+        rays, _ = ob.primary_rays(cam, W, W)
+        assert len(rays) == 262144
+        g, o = gpu.intersect_rays(rays), orc.intersect_rays(rays)
+        assert (o["tri"] >= 0).sum() > 5000
+        assert np.array_equal(g["obj"], o["obj"]) and np.array_equal(g["tri"], o["tri"]) and np.array_equal(g["t"], o["t"])
+        hit = o["obj"] >= 0
+        assert np.array_equal(g["N"][hit], o["N"][hit], equal_nan=True) and np.array_equal(g["albedo"][hit], o["albedo"][hit])
+
+    def test_tile_of_samples(self, gpu, rta, scenes, ob, full):
+        s, cam, flags, W = full
+        orc = ob.OracleScene(scenes.export_objects(s), s.I, s.L, math="portable")
+        # a tile that looks at the mesh and its reflection in the mirror floor
+        ijk = np.array([(i, j, k) for i in range(260, 308) for j in range(232, 280) for k in range(2)], np.int32)
+        p = rta.make_params(W, W, 2, flags=flags)
+        (g, tg), (o, to) = gpu.sample_trace(cam, p, ijk), orc.sample_trace(cam, p, ijk)
+        assert (to[:, 0, 1] >= 0).mean() > 0.2  # the tile sees triangles directly, and the mirror floor around them
+        rel = np.abs(g - o) / np.maximum(np.abs(o), 1e-3)
+        assert (rel > 1e-9).sum() == 0, np.sort(rel.ravel())[-5:]
+        assert np.array_equal(tg, to)

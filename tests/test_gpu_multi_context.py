@@ -35,6 +35,15 @@ def test_two_contexts_sum_to_one_render(gpu, rta, scenes):
         b.render(cam, rta.make_params(W, W, 14, spp_offset=10, flags=flags))
         a.accum_add(b)
         assert np.array_equal(got, a.accum_download(W, W), equal_nan=True)
+        # the way round a refused peer copy (pinned host buffer): the same bits
+        rta.lib.rt_debug_force_host_bounce(a._h, 1)
+        for r in (a, b):
+            r.accum_clear(W, W)
+        a.render(cam, rta.make_params(W, W, 10, spp_offset=0, flags=flags))
+        b.render(cam, rta.make_params(W, W, 14, spp_offset=10, flags=flags))
+        a.accum_add(b)
+        assert np.array_equal(got, a.accum_download(W, W), equal_nan=True)
+        rta.lib.rt_debug_force_host_bounce(a._h, 0)
         with pytest.raises(rta.RTError):
             a.accum_add(a)
     finally:

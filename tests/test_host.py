@@ -213,3 +213,16 @@ def test_reference_textures_decode_to_the_reference_texels(rta):
         img = rta.decode_jpeg(data)
         assert img.shape == (want["H"], want["W"], 3), rel
         assert hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == want["sha256"], rel
+
+
+def test_render_devices_reports_a_device_that_cannot_be_opened(rta, scenes):
+    """rt::render(scene, cam, params, image, devices) with device ids that do not exist (here: no GPU at all; on a GPU box:
+    ids beyond the device count): every thread that was started is joined, every context destroyed, and the first error
+    comes back as an exception with the HIP text - no crash, no hang, and the library still answers afterwards."""
+    W = 16
+    s, cam, flags = scenes.sphere_room(W)
+    for devices in ([99], [99, 98, 97]):
+        with pytest.raises(rta.RTError) as e:
+            rta.render_devices(s, cam, W, W, 2, devices, flags=flags)
+        assert "rt_create" in str(e.value)
+    assert b"gfx950" in rta.lib.rt_version()
