@@ -207,7 +207,9 @@ def test_converged_image_rmse(gpu, rta, scenes, ob, name, kw, spp):
     """Independent noise: the GPU image (seed 10) against the oracle image at the same sample count with another seed,
     both tone-mapped. The two only share the scene and the estimator, so their difference is noise plus bias. Stated
     bars: mean signed difference below 1 grey level of 255 (bias), RMSE no worse than 1.25 x the oracle-vs-oracle RMSE
-    of two seeds (the noise floor at this sample count) + 0.5 level. cfg2 is tested at its full 512 x 512 frame."""
+    of two seeds (the noise floor at this sample count) + 0.5 level. cfg2 is tested at its full 512 x 512 frame. At these
+    sample counts the floor is 14 to 16 levels, so this is a coarse check; the bias bar proper is test_converged_crop_* at
+    256 samples (floor 4.5 to 7 levels), and the strict check is the same-seed comparison at the end."""
     W = kw["W"]
     s, cam, flags, orc = _scene_pair(ob, scenes, getattr(scenes, name), **kw)
     gpu.upload(s)
@@ -227,6 +229,15 @@ def test_converged_image_rmse(gpu, rta, scenes, ob, name, kw, spp):
     gpu.render(cam, rta.make_params(W, W, min(spp, 4), seed=10, flags=flags))
     got = gpu.resolve(W, W, min(spp, 4))
     assert (got != same).mean() < 1e-5 and np.abs(got.astype(int) - same.astype(int)).max() <= 1
+
+
+def test_converged_crop_cfg2_256spp(gpu, rta, scenes, ob, converged_crop_check):
+    """cfg2 (sphere room, the committed estimator) at its frame size, the central 128 x 128 pixels at 256 samples: measured
+    RMSE 6.91 against a floor of 6.90 levels, bias -0.10"""
+    W = 512
+    s, cam, flags, orc = _scene_pair(ob, scenes, scenes.sphere_room, W=W)
+    gpu.upload(s)
+    converged_crop_check(gpu, rta, ob, orc, cam, flags, W, (192, 192, 320, 320), 256, "cfg2")
 
 
 def test_deterministic_room_radiance(gpu, rta, scenes, ob):
