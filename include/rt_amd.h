@@ -221,16 +221,19 @@ int rt_render(rt_ctx *ctx, const rt_camera *cam, const rt_params *p, double *acc
 int rt_sync(rt_ctx *ctx);
 
 /* rt_render for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc). It has no counterpart in the reference. Same arguments, same launches and the
- * same result bits as rt_render, but it calls no hipMalloc / hipFree: the tile counter and the sums of a launch's
+ * harnesses that forbid hipMalloc). It has no counterpart in the reference. Same arguments and the same result bits
+ * as rt_render, but it calls no hipMalloc / hipFree: the tile counter and the sums of a launch's
  * work units live in a static device array of the library (RT_STATIC_SCRATCH_BYTES for the unit sums; one copy per
- * GPU, held until the process ends) instead of buffers the context grows on demand. Limit: the unit sums of one
- * launch must fit the array, ceil(min(spp, 64) / unit) * rect pixels * 24 bytes <= RT_STATIC_SCRATCH_BYTES with the
- * unit of rt_render (8 samples from 262 144 pixels up); a call beyond it fails with RT_E_INVALID and a message that
- * says what would fit - a call of at most `unit` samples needs no unit sums and always fits. accum must be a device
- * pointer the caller owns, or NULL for the context's accumulator (allocated beforehand by rt_accum_clear). Every
- * call on one GPU shares that GPU's array: calls that overlap on one GPU - two contexts on the same device, each on
- * its own stream - race; calls on one context are ordered by its stream. */
+ * GPU, held until the process ends) instead of buffers the context grows on demand. A launch takes as many whole
+ * work units as fit the array (rect pixels * 24 bytes each, with the unit of rt_render: 8 samples from 262 144 pixels
+ * up), so a large frame is rendered in more launches of fewer samples - a 1024 x 1024 frame in launches of 16 samples
+ * instead of 64 - with the same units added in the same order, hence the same bits. Limit: a call for more than one
+ * unit of a rectangle of which not even two units fit (more than RT_STATIC_SCRATCH_BYTES / 48 = 1 398 101 pixels)
+ * fails with RT_E_INVALID and a message that says what would fit; a call of at most `unit` samples needs no unit
+ * sums and always fits. accum must be a device pointer the caller owns, or NULL for the context's accumulator
+ * (allocated beforehand by rt_accum_clear). Every call on one GPU shares that GPU's array: calls on one context are
+ * ordered by its stream; a call while ANOTHER context's static render is still running on the same GPU would race on
+ * the array and fails with RT_E_STATE instead (rt_sync the other context first). */
 #define RT_STATIC_SCRATCH_BYTES (64ull << 20)
 int rt_render_static(rt_ctx *ctx, const rt_camera *cam, const rt_params *p, double *accum);
 /* Zero / read back the context's own accumulator (W*H*3 doubles). */

@@ -17,6 +17,9 @@
 
 #include "rt_amd.h"
 #include "rt_device.hip.h"
+#include <map>
+#include <mutex>
+
 #include "rt_render_kernels.hip.h"
 #include "rt_own_bvh.hpp"
 
@@ -234,6 +237,8 @@ static int fail(rt_ctx *c, int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail((c), RT_E_DEVICE, "%s: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
+static void forget_static_owner(rt_ctx *c);
+
 static void free_scene(rt_ctx *c) {
     for (void *p : c->scene_allocs) (void)hipFree(p);
     c->scene_allocs.clear();
@@ -322,6 +327,7 @@ void rt_destroy(rt_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    forget_static_owner(c);
     free_scene(c);
     if (c->accum) (void)hipFree(c->accum);
     if (c->unit_sums) (void)hipFree(c->unit_sums);
@@ -885,6 +891,16 @@ static int unit_for(int n_slots) {
 
 /* rt_render and rt_render_static: the same launches. use_static: the tile counter and the unit sums live in this
  * device's copy of the static scratch array and nothing is allocated. */
+/* rt_render_static: the context that last used each GPU's static scratch array (overlap check in render_impl) */
+static std::mutex g_static_mutex;
+static std::map<int, rt_ctx *> g_static_owner;
+
+static void forget_static_owner(rt_ctx *c) {
+    std::lock_guard<std::mutex> lk(g_static_mutex);
+    auto it = g_static_owner.find(c->device);
+    if (it != g_static_owner.end() && it->second == c) g_static_owner.erase(it);
+}
+
 /* the scene as a counted launch gets it: with the choice of what is walked and counted (rt_debug_count_own) */
 static DScene counted_scene(const rt_ctx *c) {
     DScene d = c->sc;
@@ -913,14 +929,33 @@ static int render_impl(rt_ctx *c, const rt_camera *cam, const rt_params *p, doub
     const size_t unit_bytes = (size_t)rw * rh * 3 * sizeof(double); /* sums of one unit of every pixel of the rectangle */
     int *next_slot = c->d_next_slot;
     double *unit_sums = c->unit_sums;
+    int spp_per_launch = kSppPerLaunch;
     if (use_static) {
-        const int nk_max = p->spp < kSppPerLaunch ? p->spp : kSppPerLaunch;
-        const int n_units_max = (nk_max + unit - 1) / unit;
-        if (n_units_max > 1 && (uint64_t)n_units_max * unit_bytes > RT_STATIC_UNIT_BYTES)
+        /* The unit sums of a launch must fit the static array: a launch takes as many whole units as fit (a 1024 x 1024
+         * frame: two units of 25 MB, 16 samples per launch instead of 64). The units and the order in which they are added
+         * are those of rt_render, so the bits are the same. A rectangle so large that not even two of its units fit is
+         * refused when the call asks for more than one unit. */
+        const uint64_t units_fit = unit_bytes ? RT_STATIC_UNIT_BYTES / unit_bytes : 0;
+        if (p->spp > unit && units_fit < 2)
             return fail(c, RT_E_INVALID,
-                        "rt_render_static: %d work units of %d x %d pixels need %llu bytes of scratch, the static array holds %llu: render a smaller "
-                        "rect or at most %d samples per call (or use rt_render)",
-                        n_units_max, rw, rh, (unsigned long long)((uint64_t)n_units_max * unit_bytes), (unsigned long long)RT_STATIC_UNIT_BYTES, unit);
+                        "rt_render_static: one work unit of %d x %d pixels takes %llu bytes, the static array holds %llu: not even two units fit. "
+                        "Render a smaller rect or at most %d samples per call (or use rt_render)",
+                        rw, rh, (unsigned long long)unit_bytes, (unsigned long long)RT_STATIC_UNIT_BYTES, unit);
+        if (p->spp > unit && units_fit * (uint64_t)unit < (uint64_t)kSppPerLaunch) spp_per_launch = (int)units_fit * unit;
+        /* One array per GPU: a second context on this GPU whose static render is still running would have its tile counter
+         * and unit sums overwritten. Whoever used the array last must have finished. */
+        {
+            std::lock_guard<std::mutex> lk(g_static_mutex);
+            rt_ctx *&owner = g_static_owner[c->device];
+            if (owner && owner != c) {
+                const hipError_t q = hipStreamQuery(owner->stream);
+                if (q == hipErrorNotReady)
+                    return fail(c, RT_E_STATE, "rt_render_static: another context's rt_render_static is still running on device %d; the static "
+                                               "scratch array is shared by every context of a GPU (rt_sync the other context first)", c->device);
+                if (q != hipSuccess) (void)hipGetLastError();
+            }
+            owner = c;
+        }
         next_slot = reinterpret_cast<int *>(c->static_scratch);
         unit_sums = reinterpret_cast<double *>(c->static_scratch + RT_STATIC_HEADER);
     }
@@ -938,8 +973,8 @@ static int render_impl(rt_ctx *c, const rt_camera *cam, const rt_params *p, doub
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (span0 != c->ev0) HIPCHK(c, hipEventRecord(span0, c->stream));
     /* persistent waves: as many as stay resident, each pulling 64-pixel tiles */
-    for (int k = 0; k < p->spp; k += kSppPerLaunch) {
-        const int nk = (p->spp - k < kSppPerLaunch) ? (p->spp - k) : kSppPerLaunch;
+    for (int k = 0; k < p->spp; k += spp_per_launch) {
+        const int nk = (p->spp - k < spp_per_launch) ? (p->spp - k) : spp_per_launch;
         /* Work units: a lane takes `unit` samples of a pixel at a time, so a launch ends within one short unit per lane
          * instead of one whole pixel. */
         int chunk = nk;
@@ -1122,6 +1157,18 @@ int rt_accum_add(rt_ctx *dst, rt_ctx *src) {
     hipLaunchKernelGGL(rt_accum_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, dst->stream, dst->accum, dst->d_peer, n);
     HIPCHK(dst, hipGetLastError());
     HIPCHK(dst, hipStreamSynchronize(dst->stream)); /* the caller may clear or destroy src as soon as this returns */
+    return RT_OK;
+}
+
+/* not part of the public header: hipMemGetInfo on the context's device (tests: a call that must not allocate leaves the
+ * free bytes unchanged) */
+int rt_debug_mem_info(rt_ctx *c, uint64_t *free_bytes, uint64_t *total_bytes) {
+    if (!c || !free_bytes || !total_bytes) return RT_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t f = 0, t = 0;
+    HIPCHK(c, hipMemGetInfo(&f, &t));
+    *free_bytes = (uint64_t)f;
+    *total_bytes = (uint64_t)t;
     return RT_OK;
 }
 

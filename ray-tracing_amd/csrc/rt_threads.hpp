@@ -11,6 +11,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <exception>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -67,6 +68,8 @@ class Pool {
     uint64_t gen = 0;
     int parts = 0, pending = 0;
     bool stop = false;
+    std::exception_ptr first_error; /* of the current pass: an exception on any thread (std::bad_alloc in a builder pass) is
+                                       carried to the thread that called run() instead of ending the process */
 
     void loop(int p) {
         uint64_t seen = 0;
@@ -78,8 +81,10 @@ class Pool {
             if (p >= parts) continue;
             const std::function<void(int)> *f = fn;
             lk.unlock();
-            (*f)(p);
+            std::exception_ptr err;
+            try { (*f)(p); } catch (...) { err = std::current_exception(); }
             lk.lock();
+            if (err && !first_error) first_error = err;
             if (--pending == 0) cv_done.notify_one();
         }
     }
@@ -98,19 +103,27 @@ public:
         for (auto &t : th) t.join();
     }
     int size() const { return (int)th.size() + 1; }
-    /* f(0) .. f(n - 1), one thread each, n <= size(); the caller's thread takes 0 */
+    /* f(0) .. f(n - 1), one thread each, n <= size(); the caller's thread takes 0. An exception thrown by any f(p) is
+     * rethrown here once every thread has finished its part: the workers hold references into the caller's stack, so the
+     * pass is always waited for, and the pool is left ready for the next pass. */
     void run(int n, const std::function<void(int)> &f) {
         {
             std::lock_guard<std::mutex> lk(m);
             fn = &f; parts = n; pending = n - 1; gen++;
+            first_error = nullptr;
         }
         busy = true;
         cv_work.notify_all();
-        f(0);
+        std::exception_ptr mine;
+        try { f(0); } catch (...) { mine = std::current_exception(); }
         std::unique_lock<std::mutex> lk(m);
         cv_done.wait(lk, [&] { return pending == 0; });
         fn = nullptr;
         busy = false;
+        std::exception_ptr err = mine ? mine : first_error;
+        first_error = nullptr;
+        lk.unlock();
+        if (err) std::rethrow_exception(err);
     }
 };
 
@@ -136,10 +149,19 @@ inline void on_threads(int n, const std::function<void(int)> &f) {
     if (n <= 1) { f(0); return; }
     Pool *pool = this_threads_pool();
     if (pool && !pool->busy && n <= pool->size()) { pool->run(n, f); return; }
+    /* fresh threads: the same rule - every thread is joined before the first exception goes on to the caller */
     std::vector<std::thread> th;
-    for (int p = 1; p < n; p++) th.emplace_back([&f, p] { f(p); });
-    f(0);
+    std::vector<std::exception_ptr> err((size_t)n);
+    auto guarded = [&f, &err](int p) { try { f(p); } catch (...) { err[(size_t)p] = std::current_exception(); } };
+    try {
+        for (int p = 1; p < n; p++) th.emplace_back(guarded, p);
+    } catch (...) { /* a thread could not be started: the parts without one are run here */
+        for (int p = (int)th.size() + 1; p < n; p++) guarded(p);
+    }
+    guarded(0);
     for (auto &t : th) t.join();
+    for (const auto &e : err)
+        if (e) std::rethrow_exception(e);
 }
 
 /* fn(part, begin, end) on `parts` contiguous pieces of [0, n), one thread each */

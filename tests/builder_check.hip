@@ -32,5 +32,19 @@ int main(int argc,char**argv){
       uint64_t h=hash_tree(b); if (!h0) h0=h; else if (h!=h0){ printf("n=%lld leaf=%d: tree depends on the thread count\n",(long long)n,leaf); return 1; }
     }
   }
+  /* an exception on a worker thread or on the caller's own part reaches the caller, after every part has ended, and the
+   * pool serves the next pass; the same through threads started for the pass */
+  for (int pooled = 0; pooled < 2; pooled++) for (int thrower : {0, 2}) {
+    std::unique_ptr<rtown::PoolScope> scope;
+    if (pooled) scope.reset(new rtown::PoolScope(4));
+    std::atomic<int> ran(0);
+    bool caught = false;
+    try { rtown::on_threads(4, [&](int p) { ran++; if (p == thrower) throw std::bad_alloc(); }); }
+    catch (const std::bad_alloc &) { caught = true; }
+    if (!caught || ran != 4) { printf("exception not carried over (pooled %d, thrower %d, ran %d)\n", pooled, thrower, (int)ran); return 1; }
+    std::atomic<int> again(0);
+    rtown::on_threads(4, [&](int) { again++; });
+    if (again != 4) { printf("pool not usable after an exception\n"); return 1; }
+  }
   printf("builder checks passed\n");
 }
