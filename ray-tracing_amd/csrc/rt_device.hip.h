@@ -113,6 +113,19 @@ namespace rtd {
 #ifndef RT_SHADE_PRIO
 #define RT_SHADE_PRIO 0
 #endif
+#ifndef RT_TOP_LDS
+#define RT_TOP_LDS 0              /* 1: the four records below the filter tree's root (its children; the root itself is read with scalar
+                                     loads at feed time) are staged in the wave's LDS, and a node step all of whose records are among
+                                     them reads LDS instead of global memory */
+#endif
+#ifndef RT_PUSH_BRANCHLESS
+#define RT_PUSH_BRANCHLESS 0      /* 1: a child that is not pushed is stored to a scratch word of the lane instead of being skipped by a
+                                     branch around the store */
+#endif
+#ifndef RT_NARROW_SPLIT
+#define RT_NARROW_SPLIT 0         /* T > 32: a node step that finds 33 .. T records pops 32 of them with two lanes each and leaves the
+                                     rest for the next step, instead of a full-width step that is half empty */
+#endif
 static_assert(RT_NODE_SOFT_MIN > RT_FEED_MARGIN + RT_WAVE && RT_NODE_SOFT_MIN <= RT_NODE_SOFT, "the feed needs room for a mesh above a useful stack height");
 static_assert(RT_LEAF_CAP >= 5 * RT_WAVE, "a node step adds up to 256 leaf items (filter tree: four children) and runs only when 256 slots are free; a fed mesh adds up to 128 on top of 64");
 #define RT_PHANTOM_BASE (1 << 30)  /* best_pos values from here on: "mesh (value - base) reports a hit without a triangle" */
@@ -427,6 +440,9 @@ struct WaveLDS {
     int32_t best_pos[RT_RAY_SLOTS];       /* lowest triangle position among those with that t */
     int32_t mark[RT_WAVE];                /* triangle step: slot -> leaf item that starts there, or -1 */
     int32_t ex[RT_WAVE];                  /* triangle step: first slot of each leaf item */
+#if RT_TOP_LDS
+    float top[4][32];                     /* records 1 .. 4 of the filter tree (NodeRec4 as 32 words each) */
+#endif
     DScene sc;                            /* the render kernel's copy of its scene and frame arguments: what is used between the
                                              queries is read from here, so that it does not occupy scalar registers during them */
     RenderArgs ra;
@@ -814,11 +830,22 @@ __device__ __forceinline__ void children_step(const DScene &sc, WaveLDS *w, int 
     if (tn > sc.node_cap || tl > RT_LEAF_CAP) { /* cannot happen for a validated scene; never write past the stacks */
         if (lane == 0) atomicOr(sc.overflow, 1);
     } else {
+#if RT_PUSH_BRANCHLESS
+        uint2 *const dump = reinterpret_cast<uint2 *>(&w->mark[0]) + (lane & 31); /* mark / ex: 512 bytes that only the prefix-sum triangle step uses, never alive across a node step */
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            uint2 *pn = __builtin_amdgcn_inverse_ballot_w64(mn[c]) ? &w->node[jn[c]] : dump;
+            uint2 *pl = __builtin_amdgcn_inverse_ballot_w64(ml[c]) ? &w->leaf[jl[c]] : dump;
+            *pn = make_uint2(code[c] | ((uint32_t)rl << RT_NODE_BITS), __float_as_uint(f[c]));
+            *pl = make_uint2(code[c], leaf_word(f[c], (uint32_t)rl));
+        }
+#else
 #pragma unroll
         for (int c = 0; c < NC; c++) {
             if (__builtin_amdgcn_inverse_ballot_w64(mn[c])) w->node[jn[c]] = make_uint2(code[c] | ((uint32_t)rl << RT_NODE_BITS), __float_as_uint(f[c]));
             if (__builtin_amdgcn_inverse_ballot_w64(ml[c])) w->leaf[jl[c]] = make_uint2(code[c], leaf_word(f[c], (uint32_t)rl));
         }
+#endif
         n_nodes = tn;
         n_leaves = tl;
     }
@@ -861,6 +888,18 @@ __device__ __forceinline__ void load_children(const NodeRec4 *rec, int sub, floa
     }
 }
 
+#if RT_TOP_LDS
+/* the same from the staged copy of records 1 .. 4 (rec_m1 = record - 1, in 0 .. 3) */
+template <int NC>
+__device__ __forceinline__ void load_children_lds(const WaveLDS *w, uint32_t rec_m1, int sub, float (&bx)[6 * NC], uint32_t (&code)[NC]) {
+    const float *r = w->top[rec_m1];
+#pragma unroll
+    for (int a = 0; a < 6 * NC; a++) bx[a] = r[sub * 6 * NC + a];
+#pragma unroll
+    for (int a = 0; a < NC; a++) code[a] = __float_as_uint(r[24 + sub * NC + a]);
+}
+#endif
+
 /* One node step on a tree of four-child records (the filter tree, or the tree over a long sphere list): the top k node
  * items are popped, LPR lanes per record (k <= 64 / LPR), each lane tests 4 / LPR children of its record and pushes those
  * that its ray may hit (children_step). Branch-free up to the stores, so that all loads of the step are in flight before
@@ -893,6 +932,11 @@ __device__ __forceinline__ void own_node_step(const DScene &sc, WaveLDS *w, cons
     }
     float bx[6 * NC];
     uint32_t code[NC];
+#if RT_TOP_LDS
+    /* the first steps of a query pop nothing but children of the root: records 1 .. 4, staged in LDS */
+    if (!SPHP && sc.n_own_nodes >= 5u && (have_mask & ~wave_ballot(rec - 1u < 4u)) == 0ull) load_children_lds<NC>(w, (rec - 1u) & 3u, sub, bx, code);
+    else
+#endif
     load_children<NC>(tree4 + rec, sub, bx, code);
     if (CNT && RT_STAMP_STEPS && LPR == 1) { /* the record has arrived */
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1169,6 +1213,7 @@ __device__ __forceinline__ void pool_traverse(const DScene &sc, const DScene &co
                 int k = n_nodes < RT_WAVE ? n_nodes : RT_WAVE;
                 const int room = (node_soft - n_nodes) / 3;
                 if (k > room) k = room > 1 ? room : 1;
+                if (RT_NARROW_SPLIT > RT_WAVE / 2 && k > RT_WAVE / 2 && k <= RT_NARROW_SPLIT) k = RT_WAVE / 2;
                 /* Half a step's worth of records or fewer: two lanes share a record, each tests two of its children (their
                  * boxes are 48 consecutive bytes, their codes 8); a quarter or fewer: four lanes, one child each (24 + 4
                  * bytes) - half or a quarter of the arithmetic and pushes per lane in the steps that end a query. */
@@ -1479,7 +1524,7 @@ struct Path {
     V3 shC, shU;    /* shadow ray of the pending diffuse vertex */
     V3 T, Lsum;     /* throughput and radiance of the current path */
     V3 acc;         /* sum over the finished samples of this pixel (raytracer.cpp:1463, :1485) */
-    V3 nee, vAlbedo; /* direct light and albedo of the pending diffuse vertex */
+    V3 nee;         /* direct light of the pending diffuse vertex, times the throughput up to it */
     double sh_limit;
     uint64_t key;   /* random stream of the current sample */
     uint32_t ctr;   /* draws used so far */
@@ -1492,7 +1537,7 @@ __device__ __forceinline__ void path_begin(Path &q, int k0, bool live) {
     q.rC = mk(0, 0, 0); q.ru = mk(0, 0, 1);
     q.shC = mk(0, 0, 0); q.shU = mk(0, 0, 1);
     q.T = mk(1, 1, 1); q.Lsum = mk(0, 0, 0); q.acc = mk(0, 0, 0);
-    q.nee = q.vAlbedo = mk(0, 0, 0);
+    q.nee = mk(0, 0, 0);
     q.sh_limit = 0; q.key = 0; q.ctr = 0; q.k = k0; q.rebond = 0;
     q.lastDiffuse = false; q.shadow = false; q.segment = true; q.fresh = true; q.finished = !live;
 }
@@ -1565,11 +1610,10 @@ __device__ __forceinline__ void path_advance(const DScene &sc, SP sph, const Ren
     branch = RT_TRACE_NONE; /* what is done with the segment's hit (the probe's path trace; unused by the render kernels) */
     if (q.shadow) {
         /* raytracer.cpp:1073-1083 (or :1048-1055 for the point light): occluded iff hit before the light */
-        if (!(inter_s && hs.t < q.sh_limit)) q.Lsum = add(q.Lsum, cmul(q.T, q.nee));
+        if (!(inter_s && hs.t < q.sh_limit)) q.Lsum = add(q.Lsum, q.nee); /* nee: throughput x direct light, see the diffuse branch */
         q.shadow = false;
         if (q.segment) {
             /* color += albedo * getColor(wiRay, rebond + 1, true), raytracer.cpp:1086-1088: (h) is that ray's hit */
-            q.T = cmul(q.T, q.vAlbedo);
             q.rebond++;
             q.lastDiffuse = true;
         }
@@ -1679,7 +1723,11 @@ __device__ __forceinline__ void path_advance(const DScene &sc, SP sph, const Ren
             /* :1086-1087 */
             q.ru = random_cos_sc(sI, cI, uI2, N);
             q.rC = add(P, smul(epsilon, N));
-            q.vAlbedo = s.albedo;
+            /* The recursion adds T * direct light when the shadow ray is back and multiplies T by the albedo before the indirect
+             * ray's terms (raytracer.cpp:1082-1088). Both products have all their operands now: forming them here gives the
+             * same bits and the albedo need not be kept through the query. */
+            q.nee = cmul(q.T, q.nee);
+            q.T = cmul(q.T, s.albedo);
             q.segment = indirect;
             q.shC = shC;
             q.shU = shU;

@@ -35,6 +35,13 @@ __device__ __forceinline__ WaveLDS *wave_setup(const DScene &sc, unsigned char *
         for (int q = threadIdx.x; q < n16; q += RT_BLOCK) d16[q] = src[q];
         *sph = reinterpret_cast<const rt_sphere *>(p);
     }
+#if RT_TOP_LDS
+    if (sc.own_rec4 != nullptr && sc.n_own_nodes >= 5u) {
+        const float *src = reinterpret_cast<const float *>(sc.own_rec4 + 1);
+        float *dst = &w->top[0][0];
+        for (int q = threadIdx.x; q < 4 * 32; q += RT_BLOCK) dst[q] = src[q];
+    }
+#endif
     wave_sync();
     return w;
 }

@@ -11,6 +11,7 @@ if len(sys.argv) > 3 and sys.argv[3] == "stress":  # cfg5-like: 1 M triangles + 
 else:
     s, cam, fl, meta = scenes.battle(W=W)
 r = rta.Renderer(0); r.upload(s); r.accum_clear(W, W); r.reset_counters()
+rta.lib.rt_debug_count_own(r._h, 0 if os.environ.get("RT_PHASE_REFERENCE") else 1)  # the production traversal (filter tree) unless asked otherwise
 r.render(cam, rta.make_params(W, W, spp, flags=fl | rta.RT_F_COUNTERS)); r.sync()
 c = r.counters(); d = (C.c_uint64 * 24)(); rta.lib.rt_debug_stats(r._h, d)
 dbg = [int(x) for x in d][12:20]
