@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP64_VECTOR_TFLOPS = 78.6   # MI355X vector FP64 with every instruction an FMA = half the 157.3 TFLOP/s FP32 vector peak
 PEAK_FP32_VECTOR_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+FETCH_GATHER_FACTOR = 1.39       # bytes fetched per byte FETCH_SIZE reports, for gathers of 128-byte records (tools/calib_fetch.hip)
 
 # name -> (scene builder name, builder kwargs, frame size, samples of a step, samples of the finished image, CPU baseline samples, description)
 CONFIGS = {
@@ -354,11 +355,12 @@ def main():
             if pm.get("lib_sha16") == lib_sha16(rta.LIB_PATH) and pm.get("spp_step") == spp_step and pm.get("size") == W:
                 kk = [k for k in pm["kernels"] if kname in k][0]
                 raw = pm["kernels"][kk]["FETCH_SIZE"] * 1024.0 / pm["kernels"][kk]["dispatches"]
-                roofline["traffic"] = round(raw * 2.0, 1)
-                roofline["traffic_uncorrected"] = round(raw, 1)
-                roofline["traffic_note"] = ("HBM-side fetch bytes per launch from profiles/r3_%s_mem2.json (same library build): `traffic` with the x2 correction "
-                                            "for gfx950's 128-byte requests, which is established for wide streaming reads; this kernel gathers 64- to 128-byte "
-                                            "records, so the truth lies between `traffic_uncorrected` and `traffic`" % args.config)
+                roofline["traffic"] = round(raw * FETCH_GATHER_FACTOR, 1)
+                roofline["traffic_range"] = [round(raw, 1), round(raw * FETCH_GATHER_FACTOR, 1)]
+                roofline["traffic_note"] = ("fabric-side fetch bytes per launch from profiles/r3_%s_mem2.json (same library build). FETCH_SIZE tallies every request at "
+                                            "64 bytes; calibrated on known byte counts in this kernel's access shapes (profiles/r3_fetch_size_calibration.json): exact for "
+                                            "64-byte and smaller gathers, x1.39 for 128-byte record gathers (part of them go out as one 128-byte request), x2.0 only for "
+                                            "coalesced streaming. `traffic` uses x1.39, the lower end of `traffic_range` x1.0" % args.config)
         except (OSError, KeyError, IndexError, ValueError, ZeroDivisionError):
             pass
         sz = (ctypes.c_uint64 * 4)()
