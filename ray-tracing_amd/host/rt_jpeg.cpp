@@ -3,12 +3,16 @@
  *
  * The reference loads its textures with stbi_load(file, &W, &H, &c, 3) of the third-party stb_image v2.26 (vendored in
  * the reference tree; raytracer.cpp:762). A texel that differs by one level changes the colour of every hit that reads
- * it, so this decoder restates the arithmetic of that library's JPEG path exactly - not any other decoder's: the
- * 12-bit fixed-point "islow" inverse DCT with its two rounding stages (stb_image.h:2352-2450), coefficients and
- * dequantised products truncated to 16 bits (:2157, :2187, :3003), the 3:1 / 9:3:3:1 chroma up-sampling with its row
- * schedule (:3364-3426, :3821-3836) and the 20-bit fixed-point YCbCr conversion in which the Cb term of green is
- * masked to its upper 16 bits (:3559-3582). Entropy decoding follows ITU-T T.81 (baseline and extended sequential
- * Huffman, progressive Huffman with successive approximation, restart intervals, 8- and 16-bit quantisation tables).
+ * it, so the sample arithmetic of this decoder is that library's, not any other decoder's. Three parts are
+ * transliterated from stb_image.h (public domain, not written by the reference's author), statement by statement with
+ * its operation order and its identifiers kept, because every rounding step decides texels: the 12-bit fixed-point
+ * "islow" inverse DCT with its two rounding stages (idct1 / idct_block below: stb_image.h:2352-2450), the 3:1 / 9:3:3:1
+ * chroma up-sampling rows and their schedule (row_* and to_rgb: :3364-3426, :3802-3836) and the 20-bit fixed-point YCbCr
+ * conversion in which the Cb term of green is masked to its upper 16 bits (:3559-3582); coefficients and dequantised
+ * products are truncated to 16 bits as there (:2157, :2187, :3003). Everything else is written from ITU-T T.81: segment
+ * parsing, canonical Huffman tables, baseline and extended sequential scans, progressive scans with successive
+ * approximation, restart intervals, 8- and 16-bit quantisation tables - and, unlike that library, the checks that refuse
+ * a file before it can make the decoder read outside its planes or allocate gigabytes.
  * 8-bit samples, 1 or 3 components (grey, YCbCr, or RGB marked by component ids / an Adobe segment).
  * tests/test_host.py compares every texel with the reference's decoder on the reference's 13 texture files and on
  * generated files of every sampling layout.
