@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--total-spp", type=int, default=0, help="samples of the time-to-image render, split over the ranks (default: the configuration's)")
     ap.add_argument("--no-time-to-image", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra leg that times the single-precision render (RT_F_FAST)")
     ap.add_argument("--cpu-spp", type=int, default=0, help="samples per pixel of the CPU baseline's bounded sample (default: the configuration's, 10-20 s of CPU work)")
     ap.add_argument("--out-png", default="")
     args = ap.parse_args()
@@ -275,6 +276,34 @@ def main():
                "note": "set-up = scene construction (procedural stand-in meshes, transforms, buildBVH per mesh) with the context created beside it, then flatten + rt_upload_scene, max over ranks; "
                        "render = %d samples per pixel split over %d rank(s), reduce to rank 0, tone map, image in host memory" % (spp_image, world)}
 
+    # ---- extra leg, never `value`: the single-precision render (RT_F_FAST) of the same steps, reduce and resolve ----
+    fast = None
+    if not args.no_fast_mode and flags == 0 and info["n_spheres"] <= 64:
+        fsteps = max(1, min(args.steps, 3))
+        r.render(cam, rta.make_params(W, H, spp_step, spp_offset=0, flags=rta.RT_F_FAST), acc_ptr)  # warm-up: its triangle copy is made on first use
+        r.sync()
+        accum.zero_()
+        r.render_time_ms(reset=True)
+        barrier()
+        ta = time.perf_counter()
+        for k in range(fsteps):
+            r.render(cam, rta.make_params(W, H, spp_step, spp_offset=parallel.shard_offset(k, world, rank, spp_step), flags=rta.RT_F_FAST), acc_ptr)
+        r.sync()
+        if world > 1:
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+        if rank == 0:
+            r.resolve(W, H, spp_step * fsteps * world, acc_ptr)
+        barrier()
+        tf = torch.tensor([time.perf_counter() - ta], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(tf, op=dist.ReduceOp.MAX)
+        fk_ms, fk_n = r.render_time_ms(reset=True)
+        fast = {"Mpaths_per_s": round(float(W) * H * spp_step * fsteps * world / float(tf.item()) / 1e6, 3), "steps": fsteps,
+                "ms_per_step": round(float(tf.item()) / fsteps * 1e3, 3), "avg_launch_ms": round(fk_ms / max(1, fk_n), 3), "dtype": "f32 (sphere tests and accumulator f64)",
+                "note": "rt_params.flags = RT_F_FAST: the same estimator, random stream and traversal in single precision with FMA contraction; no bit-for-bit "
+                        "promise, held to the converged-image bars (tests/test_gpu_fast.py); an extra figure, not the metric"}
+
     if rank == 0:
         # Counted runs (separate, untimed). "production": the counted variant of the render kernel walking exactly what the
         # timed kernel walks (filter tree with single-precision box tests, any-hit shadow rays, rays without effect left out,
@@ -406,7 +435,7 @@ def main():
                           "filter_tree_records": sizes[2], "waves_per_cu": min(occ_b.value, 8), "lds_bytes_per_wave": occ_l.value,
                           "setup": setup},
                "rays_per_s": round(value * 1e6 * g["rays"] / g["paths"], 1),
-               "time_to_image": tti,
+               "time_to_image": tti, "fast_mode": fast,
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out))
     if world > 1:

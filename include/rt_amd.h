@@ -169,6 +169,13 @@ typedef struct rt_camera {
                                zero, the ray that leaves a vertex at depth max_rebond (intersected and then dropped, :960-963) -
                                with bit-identical results */
 
+#define RT_F_FAST 64u       /* rt_render only, not combinable with the other flags: the same estimator, random stream and traversal in single
+                               precision with FMA contraction. No counterpart in the reference (all double) and no bit-for-bit promise:
+                               hit identities and radiance agree with the double-precision render statistically - the converged image
+                               within the stated bias / RMSE bars - not sample by sample. Sphere lists of at most 64; the sphere tests
+                               and the accumulator stay double; the surface offsets (epsilon, shadow_bias) are raised to a few units in
+                               the last place of the hit position where the parameters are smaller */
+
 typedef struct rt_params {
     int32_t W, H;
     int32_t spp;        /* samples rendered by this call, per pixel */

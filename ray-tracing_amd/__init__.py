@@ -26,7 +26,7 @@ lib = C.CDLL(LIB_PATH)
 
 # --- PODs of include/rt_amd.h --------------------------------------------------------------------
 RT_MAT_MIRROR, RT_MAT_TRANSPARENT = 1, 2
-RT_F_POINT_LIGHT, RT_F_NO_INDIRECT, RT_F_NO_FRESNEL, RT_F_NO_JITTER, RT_F_COUNTERS, RT_F_NO_PRUNE = 1, 2, 4, 8, 16, 32
+RT_F_POINT_LIGHT, RT_F_NO_INDIRECT, RT_F_NO_FRESNEL, RT_F_NO_JITTER, RT_F_COUNTERS, RT_F_NO_PRUNE, RT_F_FAST = 1, 2, 4, 8, 16, 32, 64
 RT_TRACE_LEN = 12
 (RT_TRACE_UNUSED, RT_TRACE_NONE, RT_TRACE_LIGHT, RT_TRACE_MIRROR, RT_TRACE_TOTAL_REFLECTION, RT_TRACE_REFLECT, RT_TRACE_REFRACT,
  RT_TRACE_DIFFUSE_LIT, RT_TRACE_DIFFUSE_SHADOWED) = range(9)

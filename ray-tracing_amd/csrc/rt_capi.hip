@@ -180,6 +180,9 @@ struct rt_ctx {
     double *unit_sums = nullptr; /* sums of the work units of one launch: [unit of the pixel][H][W][3] */
     size_t unit_sums_bytes = 0;
     rt_counters *d_counters = nullptr;
+    void *d_fast_tris = nullptr;  /* RT_F_FAST: the filter tree's triangles in single precision, made at the first such render */
+    size_t fast_lds_bytes = 0;
+    int fast_waves_per_cu = 0;
     bool count_own = false; /* RT_F_COUNTERS renders walk and count the production traversal instead of the reference's */
     int *d_overflow = nullptr;
     int *d_next_slot = nullptr;
@@ -242,6 +245,8 @@ static void forget_static_owner(rt_ctx *c);
 static void free_scene(rt_ctx *c) {
     for (void *p : c->scene_allocs) (void)hipFree(p);
     c->scene_allocs.clear();
+    if (c->d_fast_tris) (void)hipFree(c->d_fast_tris);
+    c->d_fast_tris = nullptr;
     c->scene_bytes = 0;
     c->have_scene = false;
 }
@@ -840,6 +845,8 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
         const int by_regs = 4 * RT_WAVES_PER_SIMD;
         c->waves_per_cu = per_cu < by_regs ? per_cu : by_regs;
     }
+    c->fast_lds_bytes = rt_fast_lds_bytes(d.node_cap, s->n_spheres <= RT_LDS_SPHERES_MAX ? s->n_spheres : 0);
+    c->fast_waves_per_cu = rt_fast_waves_per_cu(c->fast_lds_bytes);
     c->have_scene = true;
     rtown::stage_tick("rt_upload_scene: remaining copies, occupancy");
     return RT_OK;
@@ -918,9 +925,22 @@ static int render_impl(rt_ctx *c, const rt_camera *cam, const rt_params *p, doub
         accum = c->accum;
     }
     HIPCHK(c, hipSetDevice(c->device));
+    const bool fast = (p->flags & RT_F_FAST) != 0;
+    if (fast) {
+        /* the single-precision kernel: the committed estimator only, short sphere lists, the filter tree */
+        if (p->flags != RT_F_FAST) return fail(c, RT_E_INVALID, "RT_F_FAST cannot be combined with other flags (the single-precision kernel has the committed estimator only)");
+        if (use_static) return fail(c, RT_E_INVALID, "RT_F_FAST is not available through rt_render_static (its triangle copy is allocated on first use)");
+        if (c->sc.n_spheres > RT_LDS_SPHERES_MAX) return fail(c, RT_E_INVALID, "RT_F_FAST supports sphere lists of at most %d", RT_LDS_SPHERES_MAX);
+        if (c->sc.n_meshes > 0 && c->sc.own_rec4 == nullptr) return fail(c, RT_E_STATE, "RT_F_FAST needs the filter tree, which this scene has not got");
+        if (c->sc.n_meshes > 0 && !c->d_fast_tris) {
+            const size_t nb = (size_t)c->sc.n_own_tris * rt_fast_tri_bytes();
+            if (hipMalloc(&c->d_fast_tris, nb ? nb : 1) != hipSuccess) { (void)hipGetLastError(); c->d_fast_tris = nullptr; return fail(c, RT_E_NOMEM, "RT_F_FAST: hipMalloc of %zu bytes failed", nb); }
+            HIPCHK(c, rt_fast_convert_tris(c->sc.own_tris, c->sc.n_own_tris, c->d_fast_tris, c->stream));
+        }
+    }
     const int rw = ra.j1 - ra.j0, rh = ra.i1 - ra.i0;
     const int64_t tiles = (int64_t)((rw + 7) / 8) * ((rh + 7) / 8);
-    const int64_t resident = (int64_t)c->n_cus * c->waves_per_cu;
+    const int64_t resident = (int64_t)c->n_cus * (fast ? c->fast_waves_per_cu : c->waves_per_cu);
     /* the slot counter is a 32-bit int that every resident wave may still bump by 64 once after the slots have run out */
     const int64_t slot_limit = 0x7fffffffLL - 64 * 64 * resident;
     if (tiles * RT_WAVE > slot_limit) return fail(c, RT_E_INVALID, "too many tiles");
@@ -999,7 +1019,9 @@ static int render_impl(rt_ctx *c, const rt_camera *cam, const rt_params *p, doub
         const int64_t tiles_all = tiles * (chunk < nk ? n_units : 1); /* 64-slot requests that the launch hands out */
         const unsigned pgrid = (unsigned)(tiles_all < resident ? tiles_all : resident);
         HIPCHK(c, hipMemsetAsync(next_slot, 0, sizeof(int), c->stream));
-        if (c->sc.sph_rec4 != nullptr && (p->flags & RT_F_COUNTERS))
+        if (fast)
+            HIPCHK(c, rt_fast_launch(pgrid, c->fast_lds_bytes, c->stream, c->sc, c->d_fast_tris, ra, p->spp_offset + k, nk, chunk, accum, unit_sums, next_slot, n_slots));
+        else if (c->sc.sph_rec4 != nullptr && (p->flags & RT_F_COUNTERS))
             hipLaunchKernelGGL(rt_render_spheres_kernel<true>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, counted_scene(c), ra, p->spp_offset + k, nk, chunk, accum, unit_sums, c->d_counters, next_slot, n_slots);
         else if (c->sc.sph_rec4 != nullptr)
             hipLaunchKernelGGL(rt_render_spheres_kernel<false>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, unit_sums, c->d_counters, next_slot, n_slots);
@@ -1157,6 +1179,14 @@ int rt_accum_add(rt_ctx *dst, rt_ctx *src) {
     hipLaunchKernelGGL(rt_accum_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, dst->stream, dst->accum, dst->d_peer, n);
     HIPCHK(dst, hipGetLastError());
     HIPCHK(dst, hipStreamSynchronize(dst->stream)); /* the caller may clear or destroy src as soon as this returns */
+    return RT_OK;
+}
+
+/* not part of the public header: resident waves per CU and LDS bytes per wave of the single-precision kernel with the current scene */
+int rt_debug_fast_occupancy(rt_ctx *c, int *waves_per_cu, int *lds_bytes) {
+    if (!c || !waves_per_cu || !lds_bytes || !c->have_scene) return RT_E_INVALID;
+    *waves_per_cu = c->fast_waves_per_cu;
+    *lds_bytes = (int)c->fast_lds_bytes;
     return RT_OK;
 }
 

@@ -785,8 +785,10 @@ __device__ __forceinline__ float leaf_entry(uint2 it) { return __uint_as_float(i
  * have_mask: the lanes that hold a record. item_t is the entry parameter the record was pushed with. */
 /* NC: the children a lane tests - all four of its record, or two when two lanes share a record (bx: their 6 NC box
  * coordinates, code: their codes). */
-template <int NC>
-__device__ __forceinline__ void children_step(const DScene &sc, WaveLDS *w, int lane, unsigned long long have_mask, int rl, float item_t, const float (&bx)[6 * NC],
+/* W: the wave's LDS structure - WaveLDS here; the single-precision kernel (rt_fast.hip.h) has tables of its own with the same
+ * members for the box test (rayf, tolf, thrf) and the two stacks (node, leaf) */
+template <int NC, typename W>
+__device__ __forceinline__ void children_step(const DScene &sc, W *w, int lane, unsigned long long have_mask, int rl, float item_t, const float (&bx)[6 * NC],
                                               const uint32_t (&code)[NC], int &n_nodes, int &n_leaves) {
     const float thrf = w->thrf[rl];
     const float iux = w->rayf[0][rl], iuy = w->rayf[1][rl], iuz = w->rayf[2][rl];
@@ -850,7 +852,8 @@ __device__ __forceinline__ void children_step(const DScene &sc, WaveLDS *w, int 
         n_leaves = tl;
     }
 }
-__device__ __forceinline__ void wide_children(const DScene &sc, WaveLDS *w, int lane, unsigned long long have_mask, int rl, float item_t, const float4 &q0, const float4 &q1,
+template <typename W>
+__device__ __forceinline__ void wide_children(const DScene &sc, W *w, int lane, unsigned long long have_mask, int rl, float item_t, const float4 &q0, const float4 &q1,
                                               const float4 &q2, const float4 &q3, const float4 &q4, const float4 &q5, const uint4 &ch, int &n_nodes, int &n_leaves) {
     const float bx[24] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w,
                           q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w};
@@ -890,8 +893,8 @@ __device__ __forceinline__ void load_children(const NodeRec4 *rec, int sub, floa
 
 #if RT_TOP_LDS
 /* the same from the staged copy of records 1 .. 4 (rec_m1 = record - 1, in 0 .. 3) */
-template <int NC>
-__device__ __forceinline__ void load_children_lds(const WaveLDS *w, uint32_t rec_m1, int sub, float (&bx)[6 * NC], uint32_t (&code)[NC]) {
+template <int NC, typename W>
+__device__ __forceinline__ void load_children_lds(const W *w, uint32_t rec_m1, int sub, float (&bx)[6 * NC], uint32_t (&code)[NC]) {
     const float *r = w->top[rec_m1];
 #pragma unroll
     for (int a = 0; a < 6 * NC; a++) bx[a] = r[sub * 6 * NC + a];
@@ -904,8 +907,8 @@ __device__ __forceinline__ void load_children_lds(const WaveLDS *w, uint32_t rec
  * items are popped, LPR lanes per record (k <= 64 / LPR), each lane tests 4 / LPR children of its record and pushes those
  * that its ray may hit (children_step). Branch-free up to the stores, so that all loads of the step are in flight before
  * the first is waited for: a lane without a record reads item 0 / record 0 and is masked out. */
-template <bool CNT, bool SPHP, int LPR>
-__device__ __forceinline__ void own_node_step(const DScene &sc, WaveLDS *w, const NodeRec4 *tree4, uint32_t n_recs, int lane, int k, int &n_nodes, int &n_leaves,
+template <bool CNT, bool SPHP, int LPR, typename W>
+__device__ __forceinline__ void own_node_step(const DScene &sc, W *w, const NodeRec4 *tree4, uint32_t n_recs, int lane, int k, int &n_nodes, int &n_leaves,
                                               Cnt &cnt, uint64_t &st0) {
     constexpr int NC = 4 / LPR;
     constexpr int SH = LPR == 4 ? 2 : (LPR == 2 ? 1 : 0);

@@ -89,4 +89,12 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_spheres_kerne
 extern template __global__ void rt_render_kernel<true, false>(DScene, RenderArgs, int, int, int, double *, double *, rt_counters *, int *, int);
 extern template __global__ void rt_render_spheres_kernel<true>(DScene, RenderArgs, int, int, int, double *, double *, rt_counters *, int *, int);
 
+/* rt_fast.hip: the single-precision render kernel (RT_F_FAST), compiled with FMA contraction allowed */
+size_t rt_fast_tri_bytes(void);
+size_t rt_fast_lds_bytes(int node_cap, int n_spheres);
+int rt_fast_waves_per_cu(size_t lds_bytes);
+hipError_t rt_fast_convert_tris(const rt_tri *own_tris, uint32_t n, void *out, hipStream_t stream);
+hipError_t rt_fast_launch(unsigned grid, size_t lds_bytes, hipStream_t stream, const rtd::DScene &sc, const void *ftris, const rtd::RenderArgs &ra, int k0, int nk, int chunk,
+                          double *accum, double *unit_sums, int *next_slot, int n_slots);
+
 #endif /* RT_RENDER_KERNELS_HIP_H */

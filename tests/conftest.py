@@ -40,14 +40,14 @@ def gpu(rta):
     r.close()
 
 
-def _converged_crop_check(gpu, rta, ob, orc, cam, flags, W, rect, spp, label):
+def _converged_crop_check(gpu, rta, ob, orc, cam, flags, W, rect, spp, label, gpu_flags=0):
     """Independent seeds at a high sample count on a crop of the frame: the GPU image (seed 10) against the oracle's (seed
     77), with the oracle-vs-oracle difference of seeds 77 and 78 as the noise floor. The two images share nothing but the
     scene and the estimator, so what exceeds the floor is bias. Stated bars: |mean signed difference| < 0.25 grey level of
     255, RMSE <= 1.15 x floor."""
     j0, i0, j1, i1 = rect
     gpu.accum_clear(W, W)
-    gpu.render(cam, rta.make_params(W, W, spp, seed=10, flags=flags, rect=rect))
+    gpu.render(cam, rta.make_params(W, W, spp, seed=10, flags=flags | gpu_flags, rect=rect))  # gpu_flags: RT_F_FAST for the single-precision kernel
     rows = slice(W - i1, W - i0)  # the tone map flips the rows (raytracer.cpp:1499-1501)
     g = gpu.resolve(W, W, spp)[rows, j0:j1].astype(np.float64)
     o1 = ob.resolve(orc.render(cam, rta.make_params(W, W, spp, seed=77, flags=flags, rect=rect)), spp)[rows, j0:j1].astype(np.float64)
@@ -59,6 +59,7 @@ def _converged_crop_check(gpu, rta, ob, orc, cam, flags, W, rect, spp, label):
     print("converged crop %s @%d spp: RMSE %.3f levels, noise floor %.3f (ratio %.4f), mean signed difference %.4f" % (label, spp, rmse, floor, rmse / floor, bias))
     assert abs(bias) < 0.25, bias
     assert rmse <= 1.15 * floor, (rmse, floor)
+    return rmse, floor, bias
 
 
 @pytest.fixture(scope="session")
