@@ -64,6 +64,9 @@ struct FastLDS {
     float thrf[RT_RAY_SLOTS];     /* not below the distance beyond which nothing can change the ray's answer */
     unsigned long long best[RT_RAY_SLOTS]; /* bits of the smallest accepted t (> 0: bit order = value order) << 32 | lowest position with it */
     int32_t mark[RT_WAVE];        /* scratch words (the branch-free push option of children_step) */
+#ifdef RTF_LDS_PAD /* diagnostic: fewer resident waves per CU */
+    float lds_pad[RTF_LDS_PAD / 4];
+#endif
     DScene sc;
     RenderArgs ra;
     uint2 leaf[RT_LEAF_CAP];
