@@ -180,6 +180,7 @@ struct rt_ctx {
     double *unit_sums = nullptr; /* sums of the work units of one launch: [unit of the pixel][H][W][3] */
     size_t unit_sums_bytes = 0;
     rt_counters *d_counters = nullptr;
+    bool own_failed = false;      /* the scene has triangles the reference can reach but no filter tree over them (it could not be built) */
     void *d_fast_tris = nullptr;  /* RT_F_FAST: the filter tree's triangles in single precision, made at the first such render */
     size_t fast_lds_bytes = 0;
     int fast_waves_per_cu = 0;
@@ -245,6 +246,7 @@ static void forget_static_owner(rt_ctx *c);
 static void free_scene(rt_ctx *c) {
     for (void *p : c->scene_allocs) (void)hipFree(p);
     c->scene_allocs.clear();
+    c->own_failed = false;
     if (c->d_fast_tris) (void)hipFree(c->d_fast_tris);
     c->d_fast_tris = nullptr;
     c->scene_bytes = 0;
@@ -747,7 +749,9 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
                 });
             }
             rtown::stage_tick("rt_upload_scene: leaf table, triangle subset");
+            c->own_failed = false;
             if (!keep.empty()) {
+                c->own_failed = true; /* until the tree is on the device */
                 /* Leaves of two triangles up to RT_OWN_PAIR_MAX triangles, of RT_OWN_LEAF beyond: a triangle step then runs two
                  * lanes per leaf item instead of four (fuller steps: +1.5 % on the 0.7 M-triangle scene), for 40 % more
                  * records - which is what costs on the 5 M-triangle scene (-1 %, set-up +10 %). */
@@ -781,6 +785,7 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
                     if ((rc = upload_array(c, leaf_box.data(), leaf_box.size(), &d.leaf_box32))) return rc;
                     d.n_own_nodes = (uint32_t)own.wide.size();
                     d.n_own_tris = (uint32_t)pos.size();
+                    c->own_failed = false;
                     own_depth = 3 * own.wide_depth + 2; /* stack entries the depth-first tail of a wide traversal can add */
                     HIPCHK(c, hipStreamSynchronize(c->stream));
                 }
@@ -931,8 +936,10 @@ static int render_impl(rt_ctx *c, const rt_camera *cam, const rt_params *p, doub
         if (p->flags != RT_F_FAST) return fail(c, RT_E_INVALID, "RT_F_FAST cannot be combined with other flags (the single-precision kernel has the committed estimator only)");
         if (use_static) return fail(c, RT_E_INVALID, "RT_F_FAST is not available through rt_render_static (its triangle copy is allocated on first use)");
         if (c->sc.n_spheres > RT_LDS_SPHERES_MAX) return fail(c, RT_E_INVALID, "RT_F_FAST supports sphere lists of at most %d", RT_LDS_SPHERES_MAX);
-        if (c->sc.n_meshes > 0 && c->sc.own_rec4 == nullptr) return fail(c, RT_E_STATE, "RT_F_FAST needs the filter tree, which this scene has not got");
-        if (c->sc.n_meshes > 0 && !c->d_fast_tris) {
+        /* no filter tree because no triangle can be reached (every leaf box is flat: the reference never enters one) is fine -
+         * the meshes are invisible; no filter tree because it could not be built is not */
+        if (c->sc.n_meshes > 0 && c->own_failed) return fail(c, RT_E_STATE, "RT_F_FAST needs the filter tree, which could not be built for this scene");
+        if (c->sc.n_meshes > 0 && c->sc.own_rec4 != nullptr && !c->d_fast_tris) {
             const size_t nb = (size_t)c->sc.n_own_tris * rt_fast_tri_bytes();
             if (hipMalloc(&c->d_fast_tris, nb ? nb : 1) != hipSuccess) { (void)hipGetLastError(); c->d_fast_tris = nullptr; return fail(c, RT_E_NOMEM, "RT_F_FAST: hipMalloc of %zu bytes failed", nb); }
             HIPCHK(c, rt_fast_convert_tris(c->sc.own_tris, c->sc.n_own_tris, c->d_fast_tris, c->stream));

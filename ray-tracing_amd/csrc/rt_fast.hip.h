@@ -244,7 +244,7 @@ __device__ __forceinline__ void fast_closest(const DScene &sc, const DScene &col
     const int lane = lane_id();
     fast_spheres(sph, uni(cold.n_spheres), act_a, Ca, ua, act_b, Cb, ub, ha, hb);
     beta = gamma = 0.f;
-    if (sc.n_meshes == 0) return;
+    if (sc.n_meshes == 0 || sc.own_rec4 == nullptr) return; /* no mesh, or none with a triangle that can be reached */
     /* a shadow ray that a sphere blocks before the light is settled whatever the meshes hold */
     const bool settled_b = hb.obj != INT32_MAX && hb.t < tmax_b;
     fast_tables(cold, w, lane, act_a, Ca, ua, __builtin_huge_valf(), false, ha.t);

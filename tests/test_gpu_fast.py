@@ -76,3 +76,37 @@ def test_fast_mode_refusals(gpu, rta, scenes):
         gpu.render(cam2, rta.make_params(W, W, 2, flags=rta.RT_F_FAST))
     gpu.render(cam2, rta.make_params(W, W, 2))  # the double-precision render takes the same scene
     gpu.sync()
+
+
+def test_fast_mode_on_random_scene_mixes(gpu, rta):
+    """the random scene mixes of tests/fuzz_parity.py (nested and repeated spheres, doubled / flat / repeated meshes, mirror and
+    glass everywhere) through the single-precision kernel: no stack or index fault (rt_sync reports them), and the frame's
+    radiance within a few percent of the double-precision render with the same seed - whole paths differ where a hit
+    flips, so this is a sanity bound, not a parity bar; both leaf sizes of the filter tree"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_parity.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    W, spp, done = 96, 8, 0
+    cam = rta.make_camera((0, 18, 60), 60.0, -10.0, 0.0, W)
+    for seed in range(3, 40):
+        s, verts, n_sph, n_mesh, notes = fuzz.make_scene(seed)
+        if s.flat_info()["n_spheres"] > 64:
+            continue
+        for own_leaf in (0, 4):
+            assert rta.lib.rt_debug_own_leaf(gpu._h, own_leaf) == 0
+            try:
+                gpu.upload(s)
+                (a64, i64), (af, ifast) = _pair(gpu, rta, cam, W, spp)
+                gpu.sync()
+            finally:
+                rta.lib.rt_debug_own_leaf(gpu._h, 0)
+            ok64, okf = np.isfinite(a64).all(2), np.isfinite(af).all(2)
+            assert (ok64 != okf).mean() < 0.02, (seed, own_leaf)
+            both = ok64 & okf
+            if a64[both].sum() > 0:
+                ratio = af[both].sum() / a64[both].sum()
+                assert abs(ratio - 1) < 0.05, (seed, own_leaf, ratio, notes)
+        done += 1
+    assert done >= 15
