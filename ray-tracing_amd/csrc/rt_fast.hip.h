@@ -12,8 +12,10 @@
  * five digits in the discriminant, more than a float has to spare - and the accumulator.
  *
  * Offsets: the reference leaves a surface by epsilon = 1e-5 along the normal and accepts a shadow hit below d - 1e-4
- * (raytracer.cpp:955, :1073), sized for doubles. A float position at |P| ~ 100 is known to 4e-6, so the offsets here are
- * the larger of the parameter and a few units in the last place of the position (fast_eps).
+ * (raytracer.cpp:955, :1073), sized for doubles. A float position at |P| ~ 100 is known to a few 1e-6 and rays that re-hit
+ * the surface they leave darken the image (measured: 9.4 % of the light lost at 2^-20 |P|, 1.2 % at 2^-17), so epsilon here
+ * is the larger of the parameter and 2^-15 of the hit point's largest coordinate (fast_eps), and the shadow bias keeps the
+ * reference's ratio to it (see the diffuse branch of fast_path_advance).
  */
 #pragma once
 #include "rt_device.hip.h"
@@ -44,11 +46,7 @@ __device__ __forceinline__ F3 unitf(F3 a) { /* get_normalized: no zero guard, a 
 #define RTF_PI 3.14159265358979323846f
 
 /* a uniform in (0, 1): 24 bits of the stream's draw, centred in its cell so that log() never sees zero */
-#ifdef RTF_DIAG_U53
-__device__ __forceinline__ float uniform_f(uint64_t key, uint32_t n) { return (float)((double)(rng_draw(key, n) >> 11) * (1.0 / 9007199254740992.0)); }
-#else
 __device__ __forceinline__ float uniform_f(uint64_t key, uint32_t n) { return ((float)(uint32_t)(rng_draw(key, n) >> 40) + 0.5f) * 0x1p-24f; }
-#endif
 
 /* triangle of the filter tree's order in single precision: A, e1 = B - A, e2 = C - A; pos = position in the reference's
  * visiting order (breaks exact ties in t like the double-precision kernel does, and finds the attributes) */
@@ -88,9 +86,6 @@ struct FHit {
  * reference, or a few units in the last place of the position if that is more */
 __device__ __forceinline__ float fast_eps(float param, F3 P) {
     const float m = fmaxf(fmaxf(__builtin_fabsf(P.x), __builtin_fabsf(P.y)), __builtin_fabsf(P.z));
-#ifdef RTF_DIAG_NO_EPS
-    return param;
-#endif
 #ifndef RTF_EPS_REL
 #define RTF_EPS_REL 0x1p-15f /* 256 ulp of the largest coordinate */
 #endif
@@ -323,11 +318,7 @@ __device__ __forceinline__ void fast_surface(const DScene &sc, SP sph, F3 C, F3 
 /* random_cos, raytracer.cpp:112-138 (tangent by the smallest signed component; a zero tangent gives NaNs as there) */
 __device__ __forceinline__ F3 fast_random_cos(float u1, float u2, F3 N) {
     float sn, cs;
-#ifdef RTF_DIAG_SINCOS
-    sincosf(2.f * RTF_PI * u1, &sn, &cs);
-#else
     __sincosf(2.f * RTF_PI * u1, &sn, &cs);
-#endif
     const float r = fsqrt(1.f - u2), x = cs * r, y = sn * r, z = fsqrt(u2);
     F3 T1;
     if (N.x < N.y && N.x < N.z) T1 = mkf(0, N.z, -N.y);
