@@ -493,3 +493,36 @@ def test_filter_tree_independent_of_host_threads(gpu, rta, scenes, monkeypatch):
         assert rta.lib.rt_debug_filter_tree_hash(gpu._h, C.byref(h)) == 0
         hashes.append(h.value)
     assert hashes[0] != 0 and hashes[0] == hashes[1] == hashes[2], hashes
+
+
+def test_counted_production_traversal(gpu, rta, scenes):
+    """the counted kernel variant walking what a production render walks (rt_debug_count_own: the roofline's numerator): the
+    same image bit for bit as the production kernel, four single-precision box tests per filter-tree record, far fewer
+    records and triangle tests than the reference's traversal counts, and the same rays and vertices as itself pruned on the
+    reference's trees"""
+    W = 256
+    s, cam, flags = scenes.battle(W=W, tri_scale=0.1, tex_size=64)[:3]
+    gpu.upload(s)
+    p = lambda fl: rta.make_params(W, W, 4, flags=flags | fl)
+    gpu.accum_clear(W, W)
+    gpu.render(cam, p(0))
+    want = gpu.accum_download(W, W)
+    got = {}
+    for label, own, fl in (("reference", 0, rta.RT_F_NO_PRUNE), ("pruned", 0, 0), ("production", 1, 0)):
+        assert rta.lib.rt_debug_count_own(gpu._h, own) == 0
+        try:
+            gpu.reset_counters()
+            gpu.accum_clear(W, W)
+            gpu.render(cam, p(fl | rta.RT_F_COUNTERS))
+            gpu.sync()
+            assert np.array_equal(gpu.accum_download(W, W), want, equal_nan=True), label
+            got[label] = gpu.counters()
+        finally:
+            rta.lib.rt_debug_count_own(gpu._h, 0)
+    ref, pr, prod = got["reference"], got["pruned"], got["production"]
+    assert prod["paths"] == ref["paths"] == W * W * 4
+    # the few rays whose winner is not confirmed are traced a second time, and counted as often as they are traced
+    assert pr["rays"] <= prod["rays"] <= pr["rays"] * 1.001 and pr["rays"] < ref["rays"]
+    assert prod["diffuse"] == pr["diffuse"] and prod["specular"] == pr["specular"]
+    assert prod["box_tests"] >= 4 * prod["nodes"] * 0.99 and prod["box_tests"] <= 4 * prod["nodes"] + 2 * prod["rays"] * 12  # + mesh roots and records of a second pass
+    assert 0 < prod["nodes"] < ref["nodes"] and 0 < prod["tris"] < ref["tris"]
