@@ -236,7 +236,10 @@ def main():
         image = r.resolve(W, H, spp_step * args.steps * world, acc_ptr)
     barrier()
     elapsed = time.perf_counter() - t_start
-    kernel_ms, kernel_launches = r.render_time_ms(reset=True)  # HIP events around every step's kernels, on the render stream
+    konly = ctypes.c_double(0.0)
+    rta.lib.rt_debug_kernel_time_ms(r._h, ctypes.byref(konly), None)  # HIP events around the render kernel of every launch alone
+    call_ms, kernel_launches = r.render_time_ms(reset=True)  # the same around every call: camera-ray kernel, render kernel, addition of the unit sums
+    kernel_ms = konly.value
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -341,7 +344,7 @@ def main():
         blended_peak = own_tflops / t_floor if t_floor > 0 else PEAK_FP64_VECTOR_TFLOPS
         ref_tflops = ref_flops * scale
         own_gbs = own_bytes * paths_per_launch / avg_launch_s / 1e9
-        kname = "rt_render_spheres_kernel<false>" if info["n_spheres"] > 64 else ("rt_render_kernel<false, true>" if flags == 0 else "rt_render_kernel<false, false>")
+        kname = "rt_render_spheres_kernel<false>" if info["n_spheres"] > 64 else ("rt_render_kernel<false, true, true>" if flags == 0 else "rt_render_kernel<false, false, false>")
         roofline = {
             "bound": "valu", "achieved": round(own_tflops, 4), "peak": round(blended_peak, 2), "unit": "TFLOP/s",
             "frac": round(t_floor, 5),
@@ -349,6 +352,9 @@ def main():
             "peak_fp64": PEAK_FP64_VECTOR_TFLOPS, "peak_fp32": PEAK_FP32_VECTOR_TFLOPS,
             "frac_fp64_part": round(f64 * scale / PEAK_FP64_VECTOR_TFLOPS, 5), "frac_fp32_part": round(f32 * scale / PEAK_FP32_VECTOR_TFLOPS, 5),
             "traffic": None, "kernel": kname, "avg_launch_ms": round(avg_launch_s * 1e3, 3), "launches": kernel_launches,
+            "avg_call_ms": round(call_ms / max(1, kernel_launches), 3),
+            "call_note": "avg_launch_ms: the render kernel alone; avg_call_ms: with the kernels around it in the same launch - rt_camera_rays_kernel (the launch's "
+                         "camera rays made ahead, all lanes busy; ~60 of the FP64 flops per path, counted in the numerator) and rt_units_add_kernel",
             "paths_per_launch": paths_per_launch,
             "definition": "achieved = (flops_fp64 + flops_fp32) per launch / mean launch duration (HIP events on the render stream over the timed "
                           "region); flops = what the production traversal executes, counted by the counted variant of the same kernel walking "

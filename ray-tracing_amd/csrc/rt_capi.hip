@@ -111,7 +111,24 @@ __global__ void rt_units_add_kernel(double *accum, const double *unit_sums, int 
     accum[at] = a;
 }
 
-/* dst += src over n doubles: the sum of two devices' sample ranges (rt_accum_add) */
+/* The camera rays of one launch, made ahead of it: samples k0 .. k0 + nk - 1 of every pixel of the render rectangle, one
+ * thread each, all lanes busy - inside the render kernel the same arithmetic runs with only the few lanes of a wave that
+ * start a sample in the same iteration. out is [sample][row][column][RT_CAM_RAY_DOUBLES]. */
+__global__ void __launch_bounds__(256) rt_camera_rays_kernel(RenderArgs ra, int k0, int nk, double *out) {
+    const int rw = ra.j1 - ra.j0, rh = ra.i1 - ra.i0;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)nk * rw * rh) return;
+    const int64_t npix = (int64_t)rw * rh;
+    const int s = (int)(t / npix);
+    const int pix = (int)(t - (int64_t)s * npix);
+    const int i = ra.i0 + pix / rw, j = ra.j0 + pix % rw;
+    const uint64_t key = rng_key(ra.seed_mixed, (uint32_t)(i * ra.p.W + j), (uint32_t)(k0 + s));
+    V3 rC, ru;
+    camera_ray(ra.cam, ra.p, i, j, key, rC, ru);
+    double *o = out + t * RT_CAM_RAY_DOUBLES;
+    o[0] = rC.x; o[1] = rC.y; o[2] = ru.x; o[3] = ru.y; o[4] = ru.z;
+}
+
 /* the filter tree's triangles: out[k] = tris[pos[k]], with orig_id = pos[k], the position in the reference's order */
 __global__ void rt_gather_tris_kernel(const rt_tri *tris, const int32_t *pos, uint32_t n, rt_tri *out) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -165,6 +182,10 @@ struct rt_ctx {
     /* rt_render_time_ms: event pairs of the calls since the last reset (created on demand, reused after a reset) */
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
+    /* rt_debug_kernel_time_ms: event pairs around the render kernel of each launch alone (without the camera-ray kernel before it
+     * and the unit sums' addition after it), for comparison with a profiler's per-kernel figure */
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> kev_pool;
+    size_t kev_used = 0;
     int launches_since_reset = 0;
     std::string err;
     /* scene */
@@ -179,6 +200,11 @@ struct rt_ctx {
     int accW = 0, accH = 0;
     double *unit_sums = nullptr; /* sums of the work units of one launch: [unit of the pixel][H][W][3] */
     size_t unit_sums_bytes = 0;
+    double *cam_rays = nullptr;  /* camera rays of one launch, made ahead of it (rt_camera_rays_kernel) */
+    size_t cam_rays_bytes = 0;
+    bool cam_rays_refused = false; /* an allocation failed: not tried again for this size or larger */
+    size_t cam_rays_refused_bytes = 0;
+    bool no_cam_rays = false;    /* rt_debug_camera_rays(0): the render kernels compute their camera rays themselves */
     rt_counters *d_counters = nullptr;
     bool own_failed = false;      /* the scene has triangles the reference can reach but no filter tree over them (it could not be built) */
     void *d_fast_tris = nullptr;  /* RT_F_FAST: the filter tree's triangles in single precision, made at the first such render */
@@ -338,6 +364,7 @@ void rt_destroy(rt_ctx *c) {
     free_scene(c);
     if (c->accum) (void)hipFree(c->accum);
     if (c->unit_sums) (void)hipFree(c->unit_sums);
+    if (c->cam_rays) (void)hipFree(c->cam_rays);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_overflow) (void)hipFree(c->d_overflow);
     if (c->d_next_slot) (void)hipFree(c->d_next_slot);
@@ -348,6 +375,7 @@ void rt_destroy(rt_ctx *c) {
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto &e : c->kev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -872,6 +900,9 @@ static int check_render_args(rt_ctx *c, const rt_camera *cam, const rt_params *p
     ra->cam = *cam;
     ra->p = *p;
     ra->seed_mixed = 0;
+    ra->cam_rays = nullptr;
+    ra->cam_k0 = 0;
+    ra->cam_pad = 0;
     {
         uint64_t z = p->seed + 0x9E3779B97F4A7C15ull;
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -919,6 +950,8 @@ static DScene counted_scene(const rt_ctx *c) {
     d.count_own = c->count_own ? 1 : 0;
     return d;
 }
+
+static const size_t kRtCamRayMaxBytes = (size_t)4 << 30;
 
 static int render_impl(rt_ctx *c, const rt_camera *cam, const rt_params *p, double *accum, bool use_static) {
     if (!c) return RT_E_INVALID;
@@ -1023,15 +1056,53 @@ static int render_impl(rt_ctx *c, const rt_camera *cam, const rt_params *p, doub
             unit_sums = c->unit_sums;
             if (c->unit_sums_bytes >= need) chunk = unit;
         }
+        /* The camera rays of the launch ahead of it, for the kernel of the committed estimator: kRtCamRayMaxBytes bounds the
+         * buffer (a 1024 x 1024 launch of 64 samples: 2.7 GB); larger launches, and contexts that cannot have the memory,
+         * compute the rays in the render kernel as the other kernels do. The bits are the same either way. */
+        bool pregen = false;
+        if (!fast && !use_static && !c->no_cam_rays && c->sc.sph_rec4 == nullptr && p->flags == 0) {
+            const size_t need = (size_t)nk * rw * rh * RT_CAM_RAY_DOUBLES * sizeof(double);
+            if (need <= kRtCamRayMaxBytes && c->cam_rays_bytes < need && !(c->cam_rays_refused && need >= c->cam_rays_refused_bytes)) {
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                if (c->cam_rays) (void)hipFree(c->cam_rays);
+                c->cam_rays = nullptr;
+                c->cam_rays_bytes = 0;
+                if (hipMalloc((void **)&c->cam_rays, need) == hipSuccess) c->cam_rays_bytes = need;
+                else { (void)hipGetLastError(); c->cam_rays_refused = true; c->cam_rays_refused_bytes = need; }
+            }
+            pregen = need <= kRtCamRayMaxBytes && c->cam_rays_bytes >= need;
+        }
+        ra.cam_rays = pregen ? c->cam_rays : nullptr;
+        ra.cam_k0 = p->spp_offset + k;
+        if (pregen) {
+            const int64_t nthr = (int64_t)nk * rw * rh;
+            hipLaunchKernelGGL(rt_camera_rays_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, c->stream, ra, p->spp_offset + k, nk, c->cam_rays);
+            HIPCHK(c, hipGetLastError());
+        }
         const int64_t tiles_all = tiles * (chunk < nk ? n_units : 1); /* 64-slot requests that the launch hands out */
         const unsigned pgrid = (unsigned)(tiles_all < resident ? tiles_all : resident);
         HIPCHK(c, hipMemsetAsync(next_slot, 0, sizeof(int), c->stream));
+        hipEvent_t k1 = nullptr;
+        if (!use_static && c->kev_used < 4096) {
+            if (c->kev_used == c->kev_pool.size()) {
+                hipEvent_t a = nullptr, b = nullptr;
+                if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) c->kev_pool.emplace_back(a, b);
+                else { if (a) (void)hipEventDestroy(a); (void)hipGetLastError(); }
+            }
+            if (c->kev_used < c->kev_pool.size()) {
+                HIPCHK(c, hipEventRecord(c->kev_pool[c->kev_used].first, c->stream));
+                k1 = c->kev_pool[c->kev_used].second;
+                c->kev_used++;
+            }
+        }
         if (fast)
             HIPCHK(c, rt_fast_launch(pgrid, c->fast_lds_bytes, c->stream, c->sc, c->d_fast_tris, ra, p->spp_offset + k, nk, chunk, accum, unit_sums, next_slot, n_slots));
         else if (c->sc.sph_rec4 != nullptr && (p->flags & RT_F_COUNTERS))
             hipLaunchKernelGGL(rt_render_spheres_kernel<true>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, counted_scene(c), ra, p->spp_offset + k, nk, chunk, accum, unit_sums, c->d_counters, next_slot, n_slots);
         else if (c->sc.sph_rec4 != nullptr)
             hipLaunchKernelGGL(rt_render_spheres_kernel<false>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, unit_sums, c->d_counters, next_slot, n_slots);
+        else if (pregen)
+            hipLaunchKernelGGL((rt_render_kernel<false, true, true>), dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, unit_sums, c->d_counters, next_slot, n_slots);
         else if (p->flags == 0)
             hipLaunchKernelGGL((rt_render_kernel<false, true>), dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, unit_sums, c->d_counters, next_slot, n_slots);
         else if (p->flags & RT_F_COUNTERS)
@@ -1039,6 +1110,7 @@ static int render_impl(rt_ctx *c, const rt_camera *cam, const rt_params *p, doub
         else
             hipLaunchKernelGGL(rt_render_kernel<false>, dim3(pgrid), dim3(RT_BLOCK), c->lds_bytes, c->stream, c->sc, ra, p->spp_offset + k, nk, chunk, accum, unit_sums, c->d_counters, next_slot, n_slots);
         HIPCHK(c, hipGetLastError());
+        if (k1) HIPCHK(c, hipEventRecord(k1, c->stream));
         if (chunk < nk) {
             const int64_t nthr = (int64_t)rw * rh * 3;
             hipLaunchKernelGGL(rt_units_add_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, c->stream, accum, unit_sums, n_units, p->W, p->H,
@@ -1086,7 +1158,22 @@ int rt_render_time_ms(rt_ctx *c, double *ms_total, int32_t *n_launches, int32_t 
     }
     if (ms_total) *ms_total = sum;
     if (n_launches) *n_launches = c->launches_since_reset;
-    if (reset) { c->ev_used = 0; c->launches_since_reset = 0; }
+    if (reset) { c->ev_used = 0; c->launches_since_reset = 0; c->kev_used = 0; }
+    return RT_OK;
+}
+
+/* the render kernels alone of the launches since the last reset of rt_render_time_ms (which resets this too) */
+int rt_debug_kernel_time_ms(rt_ctx *c, double *ms_total, int32_t *n_launches) {
+    if (!c || !ms_total) return RT_E_INVALID;
+    double sum = 0;
+    for (size_t k = 0; k < c->kev_used; k++) {
+        HIPCHK(c, hipEventSynchronize(c->kev_pool[k].second));
+        float f = 0;
+        HIPCHK(c, hipEventElapsedTime(&f, c->kev_pool[k].first, c->kev_pool[k].second));
+        sum += f;
+    }
+    *ms_total = sum;
+    if (n_launches) *n_launches = (int32_t)c->kev_used;
     return RT_OK;
 }
 
@@ -1319,6 +1406,13 @@ int rt_get_counters(rt_ctx *c, rt_counters *out) {
  * render walks - the filter tree with its single-precision box tests, then the reference's trees (with their extension
  * records) for the rays whose winner was not confirmed; rt_counters.box_tests / nodes / tris then count that work, and
  * word 22 of rt_debug_stats the double-precision box tests (undecided single-precision tests, winner confirmations). */
+/* test hook: 0 makes the render kernels compute their camera rays themselves (what rt_render_static and the other modes do) */
+int rt_debug_camera_rays(rt_ctx *c, int on) {
+    if (!c) return RT_E_INVALID;
+    c->no_cam_rays = !on;
+    return RT_OK;
+}
+
 int rt_debug_count_own(rt_ctx *c, int on) {
     if (!c) return RT_E_INVALID;
     c->count_own = on != 0;

@@ -428,7 +428,10 @@ struct RenderArgs {
     rt_params p;
     uint64_t seed_mixed; /* mix64(seed + golden) */
     int32_t j0, i0, j1, i1;
+    const double *cam_rays; /* camera rays made ahead of the launch (RT_CAM_RAY_DOUBLES each, [sample - cam_k0][row of the rectangle][column]), or null */
+    int32_t cam_k0, cam_pad;
 };
+#define RT_CAM_RAY_DOUBLES 5 /* origin x, y (z is the camera's) and the direction */
 
 struct WaveLDS {
     double ray[6][RT_RAY_SLOTS];          /* C, u of each ray */
@@ -1549,40 +1552,64 @@ __device__ __forceinline__ void path_begin(Path &q, int k0, bool live) {
  * up to the getColor call, raytracer.cpp:1464-1483. */
 /* PLAIN (here and below): the caller knows that no mode flag is set (the estimator as the reference has it committed), so
  * the code of the other modes is left out at compile time. */
-template <bool CNT, bool PLAIN = false>
+/* The camera ray of sample `key` of pixel (i, j) with its jitter and aperture sample: raytracer.cpp:1467-1483. Used by the
+ * render kernels and by the kernel that makes a launch's camera rays ahead of it; the arithmetic is the same
+ * instructions in both, so the rays are the same bits. */
+__device__ __forceinline__ void camera_ray(const rt_camera &cam, const rt_params &p, int i, int j, uint64_t key, V3 &rC, V3 &ru) {
+    const V3 camC = ld3(cam.C), right = ld3(cam.right), up = ld3(cam.up), view = ld3(cam.view);
+    double u1 = rng_uniform(key, 0), u2 = rng_uniform(key, 1);
+    double u3 = rng_uniform(key, 2), u4 = rng_uniform(key, 3);
+    const double4 sc13 = dev_sincos2(2 * RT_PI * u1, 2 * RT_PI * u3);
+    const double2 l24 = dev_log2(u2, u4);
+    const double s1 = sc13.x, c1 = sc13.y, s3 = sc13.z, c3 = sc13.w, l2 = l24.x, l4 = l24.y;
+    double x1 = cam.aa_sigma * c1 * sqrt(-2 * l2),
+           x2 = cam.aa_sigma * s1 * sqrt(-2 * l2);
+    double x3 = cam.dof_sigma * c3 * sqrt(-2 * l4),
+           x4 = cam.dof_sigma * s3 * sqrt(-2 * l4);
+    V3 d = mk(j - p.W / 2 + x2 + 0.5, i - p.H / 2 + x1 + 0.5, cam.zdist);
+    d = unit(d);
+    d = add(add(smul(d.x, right), smul(d.y, up)), smul(d.z, view));
+    V3 target = add(camC, smul(cam.focus, d));
+    rC = add(camC, mk(x3, x4, 0));
+    ru = unit(sub(target, rC));
+}
+
+__device__ __forceinline__ auto camera_ray_at(const RenderArgs &ra, int i, int j, int k) {
+    const int64_t at = ((int64_t)(k - ra.cam_k0) * (ra.i1 - ra.i0) + (i - ra.i0)) * (ra.j1 - ra.j0) + (j - ra.j0);
+    return in_global(ra.cam_rays) + at * RT_CAM_RAY_DOUBLES;
+}
+
+/* PREGEN: the launch's camera rays were made ahead of it (ra.cam_rays): a lane reads its ray instead of computing it with
+ * the few lanes that start a sample in the same iteration. */
+template <bool CNT, bool PLAIN = false, bool PREGEN = false>
 __device__ __forceinline__ void path_fresh(const RenderArgs &ra, Path &q, int i, int j, int kend, Cnt &cnt) {
     if (!q.fresh || q.finished) return;
     if (q.k >= kend) { q.finished = true; return; }
     const rt_params &p = ra.p;
     const rt_camera &cam = ra.cam;
-    const V3 camC = ld3(cam.C), right = ld3(cam.right), up = ld3(cam.up), view = ld3(cam.view);
     if (CNT) cnt.paths++;
     q.key = rng_key(ra.seed_mixed, (uint32_t)(i * p.W + j), (uint32_t)q.k);
     q.ctr = 0;
-    if (!PLAIN && (p.flags & RT_F_NO_JITTER)) { /* Ray r(C, u), raytracer.cpp:1482 */
+    if (PREGEN) {
+        const auto *r = camera_ray_at(ra, i, j, q.k);
+        const double r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
+        q.ctr = 4;
+        q.rC = mk(r0, r1, cam.C[2] + 0.0); /* the aperture sample moves the origin in x and y only */
+        q.ru = mk(r2, r3, r4);
+    } else if (!PLAIN && (p.flags & RT_F_NO_JITTER)) { /* Ray r(C, u), raytracer.cpp:1482 */
+        const V3 camC = ld3(cam.C), right = ld3(cam.right), up = ld3(cam.up), view = ld3(cam.view);
         V3 d = mk(j - p.W / 2 + 0.5, i - p.H / 2 + 0.5, cam.zdist);
         d = unit(d);
         const V3 dir = add(add(smul(d.x, right), smul(d.y, up)), smul(d.z, view));
         q.rC = camC; /* both branches assign rC, then ru: stores in a different order get merged into stores through a
                         selected address, and the path state then stays in scratch memory instead of registers */
         q.ru = dir;
-    } else { /* raytracer.cpp:1467-1483 */
-        double u1 = rng_uniform(q.key, 0), u2 = rng_uniform(q.key, 1);
-        double u3 = rng_uniform(q.key, 2), u4 = rng_uniform(q.key, 3);
-        const double4 sc13 = dev_sincos2(2 * RT_PI * u1, 2 * RT_PI * u3);
-        const double2 l24 = dev_log2(u2, u4);
-        const double s1 = sc13.x, c1 = sc13.y, s3 = sc13.z, c3 = sc13.w, l2 = l24.x, l4 = l24.y;
-        double x1 = cam.aa_sigma * c1 * sqrt(-2 * l2),
-               x2 = cam.aa_sigma * s1 * sqrt(-2 * l2);
-        double x3 = cam.dof_sigma * c3 * sqrt(-2 * l4),
-               x4 = cam.dof_sigma * s3 * sqrt(-2 * l4);
+    } else {
+        V3 rC, ru;
+        camera_ray(cam, p, i, j, q.key, rC, ru);
         q.ctr = 4;
-        V3 d = mk(j - p.W / 2 + x2 + 0.5, i - p.H / 2 + x1 + 0.5, cam.zdist);
-        d = unit(d);
-        d = add(add(smul(d.x, right), smul(d.y, up)), smul(d.z, view));
-        V3 target = add(camC, smul(cam.focus, d));
-        q.rC = add(camC, mk(x3, x4, 0));
-        q.ru = unit(sub(target, q.rC));
+        q.rC = rC;
+        q.ru = ru;
     }
     q.Lsum = mk(0, 0, 0);
     q.T = mk(1, 1, 1);
@@ -1804,7 +1831,7 @@ __device__ __forceinline__ V3 trace_pixel(const DScene &sc, const DScene &cold, 
  * per request; a lane keeps its pixel for all nk samples (added in order, raytracer.cpp:1464-1486), writes the
  * sum and takes the next free slot. Because lanes re-fill independently, the wave's pool stays full until the
  * whole frame runs out of pixels, instead of idling while the longest of 64 fixed pixels finishes. */
-template <bool CNT, bool SPH, bool PLAIN, typename SP>
+template <bool CNT, bool SPH, bool PLAIN, bool PREGEN = false, typename SP>
 __device__ __forceinline__ void render_persistent(const DScene &sc, const DScene &cold, WaveLDS *w, SP sph, const RootRec *roots,
                                                   const RenderArgs &ra, int k0, int nk, int chunk, double *accum, double *unit_sums, int *next_slot, int n_slots,
                                                   Cnt &cnt) {
@@ -1878,7 +1905,7 @@ __device__ __forceinline__ void render_persistent(const DScene &sc, const DScene
             const int taken = __popcll(need);
             cur = (cur + taken < end) ? cur + taken : end;
         }
-        path_fresh<CNT, PLAIN>(ra, q, i, j, kend_l, cnt);
+        path_fresh<CNT, PLAIN, PREGEN>(ra, q, i, j, kend_l, cnt);
         const bool tracing = !q.finished;
         if (wave_ballot(tracing) == 0ull) {
             if (wave_ballot(!exhausted || have) == 0ull) break;

@@ -55,6 +55,10 @@ struct FastTri {
     int32_t pos;
 };
 
+#ifndef RTF_LOOKAHEAD
+#define RTF_LOOKAHEAD 0 /* 1: full-width node steps request the next batch's records before the waiting batch is tested (two batches in flight) */
+#endif
+
 struct FastLDS {
     float ray[6][RT_RAY_SLOTS];   /* C, u of each ray */
     float rayf[6][RT_RAY_SLOTS];  /* 1/u, -(C/u): the box test's constants */
@@ -173,12 +177,29 @@ __device__ __forceinline__ void fast_pool(const DScene &sc, FastLDS *w, const Fa
         }
         wave_sync();
     }
-    while (n_nodes + n_leaves != 0) {
+#if RTF_LOOKAHEAD
+    /* a full-width batch of records whose loads are in flight while the batch before it is tested and pushed */
+    bool pend = false;
+    unsigned long long p_have = 0ull;
+    int p_rl = 0, p_k = 0;
+    float p_item_t = 0.f;
+    float p_bx[24];
+    uint32_t p_code[4];
+#pragma unroll
+    for (int a = 0; a < 24; a++) p_bx[a] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; a++) p_code[a] = RT_CHILD_EMPTY;
+#else
+    const bool pend = false;
+    const int p_k = 0;
+#endif
+    while (n_nodes + n_leaves != 0 || pend) {
         if (++steps > RT_STEP_LIMIT) {
             if (lane == 0) atomicOr(sc.overflow, 8);
             break;
         }
-        const bool do_leaf = (n_leaves >= leaf_trigger) || (n_nodes == 0) || (n_leaves + 4 * RT_WAVE > RT_LEAF_CAP);
+        const int reserved = pend ? 4 * p_k : 0; /* pushes the waiting batch may still make, on either stack */
+        const bool do_leaf = n_leaves > 0 && ((n_leaves >= leaf_trigger) || (n_nodes == 0 && !pend) || (n_leaves + reserved + 4 * RT_WAVE > RT_LEAF_CAP));
         if (do_leaf) {
             /* lane r of an item's group takes the item's r-th triangle (leaves hold at most 1 << quad_shift) */
             const int mq = n_leaves < (RT_WAVE >> quad_shift) ? n_leaves : (RT_WAVE >> quad_shift);
@@ -217,8 +238,43 @@ __device__ __forceinline__ void fast_pool(const DScene &sc, FastLDS *w, const Fa
             wave_sync();
         } else {
             int k = n_nodes < RT_WAVE ? n_nodes : RT_WAVE;
-            const int room = (node_soft - n_nodes) / 3;
+            const int room = (node_soft - n_nodes - reserved) / 3;
             if (k > room) k = room > 1 ? room : 1;
+#if RTF_LOOKAHEAD
+            if (k > RT_WAVE / 2 && room >= k && n_leaves + reserved + 4 * k <= RT_LEAF_CAP) {
+                /* pop the next full-width batch and request its records; then test and push the waiting batch while they arrive */
+                const unsigned long long in_k = wave_ballot(lane < k);
+                const uint2 it = w->node[__builtin_amdgcn_inverse_ballot_w64(in_k) ? n_nodes - 1 - lane : 0];
+                n_nodes -= k;
+                const int rl = (int)(it.x >> RT_NODE_BITS);
+                uint32_t rec = it.x & RT_LOW_MASK;
+                const unsigned long long outside = in_k & wave_ballot(rec >= n_recs);
+                if (__builtin_expect(outside != 0ull, 0)) {
+                    if (lane == 0) atomicOr(sc.overflow, 2);
+                }
+                const unsigned long long have_mask = in_k & ~outside;
+                if (!__builtin_amdgcn_inverse_ballot_w64(have_mask)) rec = 0;
+                float bx[24];
+                uint32_t code[4];
+                load_children<4>(tree4 + rec, 0, bx, code);
+                if (pend) children_step<4>(sc, w, lane, p_have, p_rl, p_item_t, p_bx, p_code, n_nodes, n_leaves);
+                pend = true;
+                p_have = have_mask; p_rl = rl; p_k = k; p_item_t = __uint_as_float(it.y);
+#pragma unroll
+                for (int a = 0; a < 24; a++) p_bx[a] = bx[a];
+#pragma unroll
+                for (int a = 0; a < 4; a++) p_code[a] = code[a];
+                wave_sync();
+                continue;
+            }
+            if (pend) { /* no full batch to start: the waiting one is finished first, its children may make one */
+                children_step<4>(sc, w, lane, p_have, p_rl, p_item_t, p_bx, p_code, n_nodes, n_leaves);
+                pend = false;
+                wave_sync();
+                continue;
+            }
+            if (n_nodes == 0) continue;
+#endif
             if (RT_NARROW_STEP > 1 && k <= RT_WAVE / 4) own_node_step<false, false, 4>(sc, w, tree4, n_recs, lane, k, n_nodes, n_leaves, cnt_unused, st_unused);
             else if (RT_NARROW_STEP > 0 && k <= RT_WAVE / 2) own_node_step<false, false, 2>(sc, w, tree4, n_recs, lane, k, n_nodes, n_leaves, cnt_unused, st_unused);
             else own_node_step<false, false, 1>(sc, w, tree4, n_recs, lane, k, n_nodes, n_leaves, cnt_unused, st_unused);

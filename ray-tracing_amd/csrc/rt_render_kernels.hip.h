@@ -47,8 +47,8 @@ __device__ __forceinline__ WaveLDS *wave_setup(const DScene &sc, unsigned char *
 }
 
 /* CNT: with work counters. PLAIN: no mode flag of rt_params is set (what a production render uses): the other modes'
- * code is left out. */
-template <bool CNT, bool PLAIN = false>
+ * code is left out. PREGEN: the launch's camera rays are read from ra.cam_rays (rt_camera_rays_kernel made them). */
+template <bool CNT, bool PLAIN = false, bool PREGEN = false>
 __global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_kernel(DScene sc, RenderArgs ra, int k0, int nk, int chunk, double *accum, double *unit_sums,
                                                              rt_counters *counters, int *next_slot, int n_slots) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_kernel(DScene
     /* this kernel is launched for sphere lists that wave_setup has staged in LDS (longer ones have a tree and the other
      * kernel): saying so lets the sphere tests read them with LDS instructions */
     const rt_sphere __attribute__((address_space(3))) *sph_lds = (const rt_sphere __attribute__((address_space(3))) *)sph;
-    render_persistent<CNT, false, PLAIN>(sc, w->sc, w, sph_lds, roots, w->ra, k0, nk, chunk, accum, unit_sums, next_slot, n_slots, cnt);
+    render_persistent<CNT, false, PLAIN, PREGEN>(sc, w->sc, w, sph_lds, roots, w->ra, k0, nk, chunk, accum, unit_sums, next_slot, n_slots, cnt);
     if (CNT) flush_counters(cnt, counters);
 }
 
@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_spheres_kerne
 /* The counted variants are instantiated in rt_counted.hip, which is compiled without the instruction scheduler option of
  * the production kernels: with it the compiler's register allocator has crashed on them (they carry ~60 more live
  * registers, the counters of every lane) after harmless changes elsewhere. */
-extern template __global__ void rt_render_kernel<true, false>(DScene, RenderArgs, int, int, int, double *, double *, rt_counters *, int *, int);
+extern template __global__ void rt_render_kernel<true, false, false>(DScene, RenderArgs, int, int, int, double *, double *, rt_counters *, int *, int);
 extern template __global__ void rt_render_spheres_kernel<true>(DScene, RenderArgs, int, int, int, double *, double *, rt_counters *, int *, int);
 
 /* rt_fast.hip: the single-precision render kernel (RT_F_FAST), compiled with FMA contraction allowed */

@@ -526,3 +526,30 @@ def test_counted_production_traversal(gpu, rta, scenes):
     assert prod["diffuse"] == pr["diffuse"] and prod["specular"] == pr["specular"]
     assert prod["box_tests"] >= 4 * prod["nodes"] * 0.99 and prod["box_tests"] <= 4 * prod["nodes"] + 2 * prod["rays"] * 12  # + mesh roots and records of a second pass
     assert 0 < prod["nodes"] < ref["nodes"] and 0 < prod["tris"] < ref["tris"]
+
+
+def test_camera_rays_made_ahead(gpu, rta, scenes, ob):
+    """rt_render makes a launch's camera rays ahead of it (one thread per sample, rt_camera_rays_kernel) where the other entry
+    points compute them in the render kernel: the same accumulator bits - full frame, a rectangle with a sample offset, and a
+    call of two launches (64 + 8 samples) - and the oracle's image on the first"""
+    W = 160
+    s, cam, flags, orc = _scene_pair(ob, scenes, scenes.mesh_room, W=W, n_tris=6000, tex_size=64)
+    assert flags == 0
+    gpu.upload(s)
+    cases = [dict(spp=3), dict(spp=5, spp_offset=11, rect=(17, 40, 150, 133)), dict(spp=72)]
+    try:
+        for kw in cases:
+            acc = {}
+            for ahead in (1, 0):
+                assert rta.lib.rt_debug_camera_rays(gpu._h, ahead) == 0
+                gpu.accum_clear(W, W)
+                gpu.render(cam, rta.make_params(W, W, flags=0, **kw))
+                acc[ahead] = gpu.accum_download(W, W)
+            assert acc[1].max() > 0
+            assert np.array_equal(acc[1].view(np.uint64), acc[0].view(np.uint64)), kw
+            if kw == cases[0]:
+                o = orc.render(cam, rta.make_params(W, W, flags=0, **kw))
+                rel = np.abs(acc[1] - o) / np.maximum(np.abs(o), 1e-300)
+                assert rel[o != 0].max() < 1e-12 and np.array_equal(acc[1] == 0, o == 0)
+    finally:
+        rta.lib.rt_debug_camera_rays(gpu._h, 1)

@@ -1,0 +1,18 @@
+"""Camera rays made ahead of the launch against rays computed in the render kernel: same bits, time of both."""
+import importlib, sys, numpy as np
+sys.path.insert(0, "/root/repo")
+rta = importlib.import_module("ray-tracing_amd"); scenes = importlib.import_module("ray-tracing_amd.scenes")
+for which, W, spp in (("battle", 1024, 64), ("sphere_room", 1024, 64), ("mesh_room", 1024, 64)):
+    if not hasattr(scenes, which): continue
+    out = getattr(scenes, which)(W=W); s, cam, flags = out[:3]
+    r = rta.Renderer(0); r.upload(s)
+    acc = {}
+    for on in (1, 0, 1, 0):
+        rta.lib.rt_debug_camera_rays(r._h, on)
+        r.accum_clear(W, W); r.render(cam, rta.make_params(W, W, spp, flags=flags)); r.sync()
+        ms, nl = r.last_render_ms()
+        a = r.accum_download(W, W)
+        print(which, "ahead" if on else "in-kernel", "%.1f Mpaths/s" % (W * W * spp / ms / 1e3), "%.3f ms" % ms, "flags", flags, flush=True)
+        acc[on] = a
+    print(which, "same bits:", np.array_equal(acc[0].view(np.uint64), acc[1].view(np.uint64)), flush=True)
+    r.close()
