@@ -8,6 +8,8 @@ W = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 if len(sys.argv) > 3 and sys.argv[3] == "stress":  # cfg5-like: 1 M triangles + 1000 spheres
     s, cam, fl = scenes.stress(W=W, n_tris=1_000_000, n_spheres=1000)
+elif len(sys.argv) > 3:  # any other scene function by name
+    s, cam, fl = getattr(scenes, sys.argv[3])(W=W)[:3]
 else:
     s, cam, fl, meta = scenes.battle(W=W)
 r = rta.Renderer(0); r.upload(s); r.accum_clear(W, W); r.reset_counters()
