@@ -1847,6 +1847,9 @@ __device__ __forceinline__ void render_persistent(const DScene &sc, const DScene
     const int n_total = n_slots * n_chunks;
     int kend_l = kend, unit_c = 0;
     bool have = false, exhausted = false;
+#ifdef RT_PROBE_LANES /* timing probe: only every RT_PROBE_LANES-th lane of a wave takes pixels (how a query's cost depends on its ray count) */
+    exhausted = (lane_id() % RT_PROBE_LANES) != 0;
+#endif
     int i = 0, j = 0;
     int cur = 0, end = 0; /* wave-uniform: the part of the last tile request not handed out yet */
     int tile_c = 0, tile_i = 0, tile_j = 0; /* wave-uniform: that request's chunk and the pixel of its tile's corner */
