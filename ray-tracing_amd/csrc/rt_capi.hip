@@ -914,7 +914,10 @@ static int check_render_args(rt_ctx *c, const rt_camera *cam, const rt_params *p
 }
 
 /* samples per kernel launch: long renders are cut into several launches of bounded duration */
-static const int kSppPerLaunch = 64;
+#ifndef RT_SPP_PER_LAUNCH
+#define RT_SPP_PER_LAUNCH 64
+#endif
+static const int kSppPerLaunch = RT_SPP_PER_LAUNCH;
 #ifndef RT_SPP_PER_UNIT
 #define RT_SPP_PER_UNIT 8
 #endif
