@@ -344,7 +344,11 @@ def main():
         blended_peak = own_tflops / t_floor if t_floor > 0 else PEAK_FP64_VECTOR_TFLOPS
         ref_tflops = ref_flops * scale
         own_gbs = own_bytes * paths_per_launch / avg_launch_s / 1e9
-        kname = "rt_render_spheres_kernel<false>" if info["n_spheres"] > 64 else ("rt_render_kernel<false, true, true>" if flags == 0 else "rt_render_kernel<false, false, false>")
+        ahead = flags == 0 and spp_step * W * H * 40 <= (4 << 30)  # the launch's camera rays are made ahead of it (rt_capi.hip: kRtCamRayMaxBytes)
+        if info["n_spheres"] > 64:
+            kname = "rt_render_spheres_kernel<false, %s>" % ("true" if ahead else "false")
+        else:
+            kname = "rt_render_kernel<false, true, true>" if ahead else ("rt_render_kernel<false, true, false>" if flags == 0 else "rt_render_kernel<false, false, false>")
         roofline = {
             "bound": "valu", "achieved": round(own_tflops, 4), "peak": round(blended_peak, 2), "unit": "TFLOP/s",
             "frac": round(t_floor, 5),

@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_kernel(DScene
 }
 
 /* the same for scenes whose sphere list is too long for LDS: with the walk through the sphere tree compiled in */
-template <bool CNT>
+template <bool CNT, bool PREGEN = false>
 __global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_spheres_kernel(DScene sc, RenderArgs ra, int k0, int nk, int chunk, double *accum, double *unit_sums,
                                                                      rt_counters *counters, int *next_slot, int n_slots) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_spheres_kerne
     Cnt cnt = {};
     if (threadIdx.x == 0) { w->sc = sc; w->ra = ra; }
     wave_sync();
-    render_persistent<CNT, true, false>(sc, w->sc, w, sph, roots, w->ra, k0, nk, chunk, accum, unit_sums, next_slot, n_slots, cnt);
+    render_persistent<CNT, true, false, PREGEN>(sc, w->sc, w, sph, roots, w->ra, k0, nk, chunk, accum, unit_sums, next_slot, n_slots, cnt);
     if (CNT) flush_counters(cnt, counters);
 }
 
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_OCCUPANCY rt_render_spheres_kerne
  * the production kernels: with it the compiler's register allocator has crashed on them (they carry ~60 more live
  * registers, the counters of every lane) after harmless changes elsewhere. */
 extern template __global__ void rt_render_kernel<true, false, false>(DScene, RenderArgs, int, int, int, double *, double *, rt_counters *, int *, int);
-extern template __global__ void rt_render_spheres_kernel<true>(DScene, RenderArgs, int, int, int, double *, double *, rt_counters *, int *, int);
+extern template __global__ void rt_render_spheres_kernel<true, false>(DScene, RenderArgs, int, int, int, double *, double *, rt_counters *, int *, int);
 
 /* rt_fast.hip: the single-precision render kernel (RT_F_FAST), compiled with FMA contraction allowed */
 size_t rt_fast_tri_bytes(void);

@@ -528,12 +528,14 @@ def test_counted_production_traversal(gpu, rta, scenes):
     assert 0 < prod["nodes"] < ref["nodes"] and 0 < prod["tris"] < ref["tris"]
 
 
-def test_camera_rays_made_ahead(gpu, rta, scenes, ob):
+@pytest.mark.parametrize("builder,kw", [("mesh_room", dict(n_tris=6000, tex_size=64)), ("stress", dict(n_tris=8000, n_spheres=150))],
+                         ids=["short_sphere_list", "long_sphere_list"])
+def test_camera_rays_made_ahead(gpu, rta, scenes, ob, builder, kw):
     """rt_render makes a launch's camera rays ahead of it (one thread per sample, rt_camera_rays_kernel) where the other entry
     points compute them in the render kernel: the same accumulator bits - full frame, a rectangle with a sample offset, and a
-    call of two launches (64 + 8 samples) - and the oracle's image on the first"""
+    call of two launches (64 + 8 samples) - and the oracle's image on the first; both render kernels that read the rays"""
     W = 160
-    s, cam, flags, orc = _scene_pair(ob, scenes, scenes.mesh_room, W=W, n_tris=6000, tex_size=64)
+    s, cam, flags, orc = _scene_pair(ob, scenes, getattr(scenes, builder), W=W, **kw)
     assert flags == 0
     gpu.upload(s)
     cases = [dict(spp=3), dict(spp=5, spp_offset=11, rect=(17, 40, 150, 133)), dict(spp=72)]

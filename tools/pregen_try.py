@@ -2,8 +2,10 @@
 import importlib, sys, numpy as np
 sys.path.insert(0, "/root/repo")
 rta = importlib.import_module("ray-tracing_amd"); scenes = importlib.import_module("ray-tracing_amd.scenes")
-for which, W, spp in (("battle", 1024, 64), ("sphere_room", 1024, 64), ("mesh_room", 1024, 64)):
-    if not hasattr(scenes, which): continue
+cases = (("battle", 1024, 64), ("sphere_room", 1024, 64), ("mesh_room", 1024, 64))
+if len(sys.argv) > 1:
+    cases = tuple(c for c in cases + (("stress", 2048, 64),) if c[0] in sys.argv[1:])
+for which, W, spp in cases:
     out = getattr(scenes, which)(W=W); s, cam, flags = out[:3]
     r = rta.Renderer(0); r.upload(s)
     acc = {}
