@@ -809,8 +809,25 @@ int rt_upload_scene(rt_ctx *c, const rt_scene_desc *s) {
                     HIPCHK(c, e);
                     d.own_tris = (const rt_tri *)d_own;
                     if ((rc = upload_array(c, own.wide.data(), own.wide.size(), &d.own_rec4))) return rc;
+#if !RT_TRI_FIN
                     if ((rc = upload_array(c, tri_leaf.data(), tri_leaf.size(), &d.tri_leaf))) return rc;
                     if ((rc = upload_array(c, leaf_box.data(), leaf_box.size(), &d.leaf_box32))) return rc;
+#else
+                    {
+                        rtown::raw_vector<TriFin> fin((size_t)s->n_tris);
+                        rtown::parallel_parts(s->n_tris, tri_thr, [&](int, int64_t k0, int64_t k1) {
+                            for (int64_t k = k0; k < k1; k++) {
+                                TriFin &f = fin[(size_t)k];
+                                const int32_t lf = tri_leaf[(size_t)k];
+                                for (int a = 0; a < 6; a++) f.box[a] = lf >= 0 ? leaf_box[(size_t)lf * 6 + a] : 0.f;
+                                f.object_id = s->meshes[s->tris[k].mesh].object_id;
+                                f.group = s->attrs[k].group;
+                            }
+                        });
+                        if ((rc = upload_array(c, fin.data(), fin.size(), &d.tri_fin))) return rc;
+                        HIPCHK(c, hipStreamSynchronize(c->stream));
+                    }
+#endif
                     d.n_own_nodes = (uint32_t)own.wide.size();
                     d.n_own_tris = (uint32_t)pos.size();
                     c->own_failed = false;

@@ -164,6 +164,16 @@ struct NodeRec4 {
     uint32_t pad[4];
 };
 
+#ifndef RT_TRI_FIN
+#define RT_TRI_FIN 1 /* 1: the epilogue of a query reads the winner's leaf box, object id and texture group from one record per triangle
+                        instead of triangle -> (leaf index, mesh) -> (leaf box, object id): one dependent load less */
+#endif
+struct TriFin { /* 32 bytes */
+    float box[6];      /* the box of the reference leaf that holds the triangle, rounded to float (to nearest) */
+    int32_t object_id; /* of the triangle's mesh */
+    int32_t group;     /* rt_tri_attr::group */
+};
+
 struct DScene {
     const rt_sphere *spheres;
     const RootRec *roots;
@@ -175,6 +185,7 @@ struct DScene {
     const rt_tri *own_tris;   /* triangles in the filter tree's order; orig_id holds the position in `tris` */
     const int32_t *tri_leaf;  /* by triangle position: index of the reference leaf that holds it */
     const float *leaf_box32;  /* 6 floats per reference leaf: its box rounded to float (to nearest) */
+    const TriFin *tri_fin;    /* by triangle position: what settles a hit on that triangle, in one record (RT_TRI_FIN) */
     uint32_t n_own_nodes;
     uint32_t n_own_tris;      /* triangles in own_tris: those the reference's traversal can reach */
     const rt_tri *tris;       /* by triangle position (80 bytes each: a leaf's triangles are contiguous) */
@@ -702,12 +713,24 @@ __device__ __forceinline__ void rays_end(const DScene &sc, WaveLDS *w, int lane,
         const uint32_t p0 = tr[r] ? (uint32_t)pos[r] : 0u;
         T[r] = tri_load(in_global(sc.tris), p0);
         mesh[r] = in_global(sc.tris)[p0].mesh;
-        if (r == 0) group = in_global(sc.attrs)[p0].group; /* only a path segment's hit is shaded */
-        if (own) leaf[r] = in_global(sc.tri_leaf)[p0];
+#if RT_TRI_FIN
+        if (own) { /* everything else about the triangle in the same round trip */
+            const auto *f = in_global(sc.tri_fin) + p0;
+            for (int a = 0; a < 6; a++) lb[r][a] = f->box[a];
+            oid[r] = f->object_id;
+            if (r == 0) group = f->group;
+            if (ph[r]) oid[r] = in_global(sc.meshes)[pos[r] - RT_PHANTOM_BASE].object_id;
+        } else
+#endif
+        {
+            if (r == 0) group = in_global(sc.attrs)[p0].group; /* only a path segment's hit is shaded */
+            if (own) leaf[r] = in_global(sc.tri_leaf)[p0];
+        }
     }
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         if (!tr[r]) mesh[r] = ph[r] ? pos[r] - RT_PHANTOM_BASE : 0;
+        if (RT_TRI_FIN && own) continue;
         oid[r] = in_global(sc.meshes)[mesh[r]].object_id;
         if (own) {
             const float *b = in_global(sc.leaf_box32) + (size_t)leaf[r] * 6;
